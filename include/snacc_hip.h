@@ -1,0 +1,112 @@
+/*
+ * snacc_hip.h -- C-ABI of libsnacc_hip.so: the MI355X (gfx950) backend for the
+ * all-pairs lz4 normalized-compression-distance hot path of alexsweeten/snacc.
+ *
+ * The reference has no FFI; its hot path is Python calling the third-party
+ * codec once per file / ordered file pair:
+ *
+ *   ref:snacc/pairwise_ncd.py:69,80,90   bytes(seq) -> lz4framed.compress -> getsizeof
+ *   ref:snacc/cli.py:108-116             phase A: N single compressions
+ *   ref:snacc/cli.py:120-129             phase B: N*N ordered-pair compressions
+ *
+ * This library replaces exactly those calls with batched ones.  It returns raw
+ * LZ4-frame lengths (liblz4 1.9.3 LZ4F_compressFrame, NULL preferences, bit
+ * exact); the "+33" of sys.getsizeof and the float64 NCD formula
+ * (ref:snacc/pairwise_ncd.py:93-111) stay in Python.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no C++/torch types cross the ABI.
+ *  - every function returns 0 on success or a negative SNK_E_* code; it never
+ *    throws or aborts.  snk_last_error() gives a message for the last failure.
+ *  - the caller owns every host buffer; the library never keeps a host pointer
+ *    after a call returns.  The library owns its device memory.
+ *  - one snk_ctx is used from one thread at a time; contexts are independent.
+ *  - there is NO CPU fallback: without a HIP device every entry point that
+ *    computes fails with SNK_E_HIP.
+ */
+#ifndef SNACC_HIP_H
+#define SNACC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNK_ABI_VERSION 1
+
+enum {
+    SNK_OK        = 0,
+    SNK_E_ARG     = -1,   /* bad argument                                   */
+    SNK_E_HIP     = -2,   /* HIP runtime error (no device, OOM, launch ...) */
+    SNK_E_STATE   = -3,   /* call order (e.g. pairs before upload)          */
+    SNK_E_TOOBIG  = -4,   /* a sequence or a concatenation >= 0x7E000000 B  */
+    SNK_E_KERNEL  = -5    /* device-side consistency check failed           */
+};
+
+typedef struct snk_ctx snk_ctx;
+
+/* ABI version of the loaded library (SNK_ABI_VERSION). */
+int snk_version(void);
+
+/* Message of the last failure on `ctx` (or of the last failed snk_ctx_create
+ * when ctx == NULL).  Valid until the next call on the same context. */
+const char *snk_last_error(const snk_ctx *ctx);
+
+/* Create a context bound to HIP device `device` (index as seen by this process). */
+int snk_ctx_create(int device, snk_ctx **out);
+void snk_ctx_destroy(snk_ctx *ctx);
+
+/* Tunables (all optional).  Keys:
+ *   "fast_lanes"    chains (lanes) per wavefront in the 2-bit ACGT kernel
+ *   "fast_waves"    wavefronts per workgroup in the 2-bit ACGT kernel
+ *   "force_generic" 1 = route every pair through the byte kernel (testing)
+ *   "content_size"  1 = add the 8-byte content-size field to every frame
+ *                   (py-lz4framed builds that set it)        */
+int snk_set_option(snk_ctx *ctx, const char *key, long value);
+
+/* Replaces the per-task FASTA->bytes hand-off of ref:snacc/pairwise_ncd.py:59-69.
+ * Copies `n_seq` byte strings (the concatenated residues of each input file, as
+ * extract_sequences returns them) to the device, classifies them (pure
+ * upper-case ACGT -> 2-bit packed), and computes every single-sequence frame
+ * size plus the per-sequence prefix snapshots the pair kernels start from.
+ * A second upload on the same context replaces the first. */
+int snk_upload(snk_ctx *ctx, int n_seq, const uint8_t *const *seqs, const uint64_t *lens);
+
+/* Number of sequences resident / how many of them took the 2-bit path. */
+int snk_num_sequences(const snk_ctx *ctx);
+int snk_num_packed(const snk_ctx *ctx);
+
+/* Phase A (ref:snacc/cli.py:108-116): sizes[i] = len(lz4framed.compress(seq_i)). */
+int snk_singles(snk_ctx *ctx, uint32_t *sizes /* [n_seq], host */);
+
+/* Phase B (ref:snacc/cli.py:120-129) for rows [row_begin, row_end):
+ *   sizes[(i-row_begin)*n_seq + j] = len(lz4framed.compress(seq_i + seq_j)).
+ * Blocking; result copied to host memory. */
+int snk_pairs(snk_ctx *ctx, int row_begin, int row_end, uint32_t *sizes /* host */);
+
+/* Same, asynchronous: launches on `hip_stream` (a hipStream_t passed as void*,
+ * NULL = the context's own stream) and writes u32 sizes to DEVICE memory
+ * `d_sizes` ((row_end-row_begin)*n_seq elements), e.g. a torch tensor that is
+ * then all-gathered over RCCL.  Does not synchronise.  The device-side status
+ * word is checked by the next blocking call or by snk_sync(). */
+int snk_pairs_device(snk_ctx *ctx, int row_begin, int row_end, void *d_sizes, void *hip_stream);
+
+/* Arbitrary ordered pairs: sizes[t] = len(compress(seq[ij[2t]] + seq[ij[2t+1]])).
+ * Used by compressed_size((a, b), "lz4") (one pair per call in the reference). */
+int snk_pairs_list(snk_ctx *ctx, int n_pairs, const int32_t *ij, uint32_t *sizes /* host */);
+
+/* Wait for outstanding work on the context's stream / the given stream and
+ * return SNK_E_KERNEL if any launch since the last check flagged an error. */
+int snk_sync(snk_ctx *ctx, void *hip_stream);
+
+/* Device time (ms, hipEvent pair around the kernels on their stream) of the
+ * last snk_pairs / snk_pairs_device / snk_pairs_list call; for
+ * snk_pairs_device it is valid after snk_sync().  Returns < 0 if unavailable. */
+double snk_last_pairs_ms(snk_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNACC_HIP_H */

@@ -1,0 +1,15 @@
+"""CPU oracle for the lz4 NCD hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package.  The product (``snacc_amd``) never does.
+
+* ``lz4f_oracle.c``  -- C restatement of liblz4 1.9.3 ``LZ4F_compressFrame(prefs=NULL)``
+  (size only), the arithmetic behind ``lz4framed.compress`` at
+  ref:snacc/pairwise_ncd.py:80.
+* ``ncd_oracle.py``  -- Python restatement of ref:snacc/pairwise_ncd.py (sequence
+  extraction, ``+33`` getsizeof, NCD formula) and ref:snacc/cli.py:102-142 (pair
+  set, matrix layout).
+* ``liblz4_ref.py``  -- optional ctypes binding to the liblz4 1.9.3 *binary* of the
+  image, used to pin the C restatement (differential fuzz).  Test-only.
+"""
+from .loader import lib, build, lz4f_size, lz4f_size_pair, lcg_genome, lcg_mutant  # noqa: F401

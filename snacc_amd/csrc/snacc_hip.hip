@@ -1,0 +1,528 @@
+// snacc_hip.hip -- C-ABI (include/snacc_hip.h) over the gfx950 kernels in
+// snk_device.hip.h.  Host logic only: device memory, job lists, launches.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -fPIC -shared -I../../include \
+//               -o ../libsnacc_hip.so snacc_hip.hip
+#include "snk_device.hip.h"
+#include "snacc_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct snk_ctx_impl {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    std::string err;
+
+    // options
+    int fast_lanes = 9, fast_waves = 4, gen_chains = 8;
+    bool force_generic = false;
+    uint32_t header_bytes = 7;
+
+    // resident sequences
+    int n = 0, n_packed = 0;
+    std::vector<uint32_t> len;
+    std::vector<uint8_t> is_packed;
+    uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_zero = nullptr;
+    const uint8_t **d_bytes_ptr = nullptr, **d_packed_ptr = nullptr;
+    uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
+    uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
+    uint32_t *d_lut_partner = nullptr, *d_lut_hash = nullptr;
+    uint32_t *d_single = nullptr, *d_status = nullptr;
+    bool singles_done = false;
+
+    // scratch for pair launches (grown on demand)
+    SnkJob *d_jobs = nullptr; size_t jobs_cap = 0;
+    uint32_t *d_out = nullptr; size_t out_cap = 0;
+    std::vector<SnkJob> h_jobs;
+};
+
+int fail(snk_ctx_impl *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), SNK_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+template <typename T> void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
+
+void free_sequences(snk_ctx_impl *c)
+{
+    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_ptr);
+    dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast);
+    dfree(c->d_snap_gen); dfree(c->d_single);
+    c->n = 0; c->n_packed = 0; c->len.clear(); c->is_packed.clear(); c->singles_done = false;
+}
+
+// ---- the 5-mer LUTs of the 2-bit kernel ---------------------------------------------------
+// code = (byte >> 1) & 3  =>  A=0 C=1 T=2 G=3
+const char kCodeToByte[4] = { 'A', 'C', 'T', 'G' };
+
+uint32_t host_hash5(const uint8_t *p)
+{
+    uint64_t v = 0;
+    memcpy(&v, p, 5);
+    return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
+}
+
+bool build_luts(std::vector<uint32_t> &partner, std::vector<uint32_t> &hash)
+{
+    partner.assign(1024, 0); hash.assign(1024, 0);
+    std::vector<std::vector<uint32_t>> cls(4096);
+    for (uint32_t k = 0; k < 1024; ++k) {
+        uint8_t b[5];
+        for (int i = 0; i < 5; ++i) b[i] = (uint8_t)kCodeToByte[(k >> (2 * i)) & 3];
+        hash[k] = host_hash5(b);
+        cls[hash[k]].push_back(k);
+    }
+    for (uint32_t k = 0; k < 1024; ++k) {
+        const auto &m = cls[hash[k]];
+        if (m.size() > 4) return false;              // would not fit 3 partners (never for this hash)
+        uint32_t p[3] = { k, k, k };
+        int t = 0;
+        for (uint32_t o : m) if (o != k) p[t++] = o;
+        partner[k] = p[0] | (p[1] << 10) | (p[2] << 20);
+    }
+    return true;
+}
+
+SnkTables make_tables(const snk_ctx_impl *c)
+{
+    SnkTables T;
+    T.bytes = c->d_bytes_ptr; T.packed = c->d_packed_ptr; T.len = c->d_len;
+    T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
+    T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
+    T.lut_partner = c->d_lut_partner; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
+    return T;
+}
+
+int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
+{
+    if (n_jobs > c->jobs_cap) {
+        dfree(c->d_jobs);
+        HIPCHK(c, hipMalloc((void **)&c->d_jobs, n_jobs * sizeof(SnkJob)));
+        c->jobs_cap = n_jobs;
+    }
+    if (n_out > c->out_cap) {
+        dfree(c->d_out);
+        HIPCHK(c, hipMalloc((void **)&c->d_out, n_out * sizeof(uint32_t)));
+        c->out_cap = n_out;
+    }
+    return SNK_OK;
+}
+
+// Launch both kernels over a job list.  jobs[0 .. n_fast) go to the 2-bit kernel,
+// jobs[n_fast .. n_fast+n_gen) to the byte kernel.  `d_jobs` already on device.
+int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_fast, size_t n_gen,
+                uint32_t *d_out)
+{
+    SnkTables T = make_tables(c);
+    if (n_fast) {
+        const uint32_t lanes = (uint32_t)c->fast_lanes, waves = (uint32_t)c->fast_waves;
+        const uint32_t chains = lanes * waves;
+        const size_t lds = (size_t)(1 + chains) * 4096;
+        HIPCHK(c, hipFuncSetAttribute((const void *)snk_fast_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
+        hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                           T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (n_gen) {
+        const uint32_t chains = (uint32_t)c->gen_chains;
+        const size_t lds = (size_t)chains * 16384;
+        HIPCHK(c, hipFuncSetAttribute((const void *)snk_generic_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t grid = (uint32_t)((n_gen + chains - 1) / chains);
+        hipLaunchKernelGGL(snk_generic_kernel, dim3(grid), dim3(64), lds, st,
+                           T, d_jobs + n_fast, (uint32_t)n_gen, chains, d_out, c->d_status);
+        HIPCHK(c, hipGetLastError());
+    }
+    return SNK_OK;
+}
+
+int check_status(snk_ctx_impl *c)
+{
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) {
+        (void)hipMemset(c->d_status, 0, sizeof(uint32_t));
+        return fail(c, SNK_E_KERNEL, "device-side check failed (status 0x%x)", st);
+    }
+    return SNK_OK;
+}
+
+bool pair_is_fast(const snk_ctx_impl *c, int i, int j)
+{
+    return !c->force_generic && c->is_packed[i] && c->is_packed[j] &&
+           (uint64_t)c->len[i] + c->len[j] > SNK_BLOCK;
+}
+
+// Build the job list for an arbitrary set of ordered pairs (i, j) -> out index.
+// Fast jobs are ordered by suffix sequence j so that the chains of one workgroup
+// walk the same bytes (L1/L2 locality); generic jobs follow.
+template <typename PairAt>
+int build_jobs(snk_ctx_impl *c, size_t n_pairs, PairAt pair_at, size_t &n_fast, size_t &n_gen)
+{
+    std::vector<SnkJob> fast, gen;
+    fast.reserve(n_pairs);
+    for (size_t t = 0; t < n_pairs; ++t) {
+        int i, j; uint32_t o;
+        pair_at(t, i, j, o);
+        if (i < 0 || j < 0 || i >= c->n || j >= c->n) return fail(c, SNK_E_ARG, "pair index out of range");
+        if ((uint64_t)c->len[i] + c->len[j] >= 0x7E000000ull)
+            return fail(c, SNK_E_TOOBIG, "concatenation of %d and %d too long", i, j);
+        SnkJob jb; jb.xi = i; jb.yi = j; jb.out_idx = o; jb.snap = 0;
+        (pair_is_fast(c, i, j) ? fast : gen).push_back(jb);
+    }
+    n_fast = fast.size(); n_gen = gen.size();
+    c->h_jobs.swap(fast);
+    c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
+    return SNK_OK;
+}
+
+int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_gen, uint32_t *d_out)
+{
+    const size_t nj = n_fast + n_gen;
+    if (nj == 0) return SNK_OK;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), nj * sizeof(SnkJob), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    int rc = launch_jobs(c, st, c->d_jobs, n_fast, n_gen, d_out);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    c->ev_valid = true;
+    return SNK_OK;
+}
+
+} // namespace
+
+struct snk_ctx : snk_ctx_impl {};
+
+extern "C" {
+
+int snk_version(void) { return SNK_ABI_VERSION; }
+
+const char *snk_last_error(const snk_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int snk_ctx_create(int device, snk_ctx **out)
+{
+    if (!out) return fail(nullptr, SNK_E_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SNK_E_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, SNK_E_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    snk_ctx *c = new (std::nothrow) snk_ctx();
+    if (!c) return fail(nullptr, SNK_E_HIP, "out of host memory");
+    c->device = device;
+#define CRCHK(call)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            fail(nullptr, SNK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));             \
+            snk_ctx_destroy(c);                                                                  \
+            return SNK_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+    CRCHK(hipSetDevice(device));
+    CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRCHK(hipEventCreate(&c->ev0));
+    CRCHK(hipEventCreate(&c->ev1));
+    CRCHK(hipMalloc((void **)&c->d_status, sizeof(uint32_t)));
+    CRCHK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+    CRCHK(hipMalloc((void **)&c->d_zero, 4 * SNK_PAD));
+    CRCHK(hipMemset(c->d_zero, 0, 4 * SNK_PAD));
+    {
+        std::vector<uint32_t> partner, hash;
+        if (!build_luts(partner, hash)) {
+            fail(nullptr, SNK_E_STATE, "5-mer collision class larger than 4");
+            snk_ctx_destroy(c);
+            return SNK_E_STATE;
+        }
+        CRCHK(hipMalloc((void **)&c->d_lut_partner, 1024 * sizeof(uint32_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_hash, 1024 * sizeof(uint32_t)));
+        CRCHK(hipMemcpy(c->d_lut_partner, partner.data(), 4096, hipMemcpyHostToDevice));
+        CRCHK(hipMemcpy(c->d_lut_hash, hash.data(), 4096, hipMemcpyHostToDevice));
+    }
+#undef CRCHK
+    *out = c;
+    return SNK_OK;
+}
+
+void snk_ctx_destroy(snk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_sequences(c);
+    dfree(c->d_zero); dfree(c->d_lut_partner); dfree(c->d_lut_hash); dfree(c->d_status);
+    dfree(c->d_jobs); dfree(c->d_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int snk_set_option(snk_ctx *c, const char *key, long value)
+{
+    if (!c || !key) return fail(c, SNK_E_ARG, "NULL argument");
+    std::string k(key);
+    if (k == "fast_lanes") {
+        if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "fast_lanes must be 1..64");
+        c->fast_lanes = (int)value;
+    } else if (k == "fast_waves") {
+        if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "fast_waves must be 1..16");
+        c->fast_waves = (int)value;
+    } else if (k == "gen_chains") {
+        if (value < 1 || value > 9) return fail(c, SNK_E_ARG, "gen_chains must be 1..9");
+        c->gen_chains = (int)value;
+    } else if (k == "force_generic") {
+        c->force_generic = value != 0;
+    } else if (k == "content_size") {
+        if (c->n) return fail(c, SNK_E_STATE, "content_size must be set before snk_upload");
+        c->header_bytes = value ? 15u : 7u;
+    } else {
+        return fail(c, SNK_E_ARG, "unknown option '%s'", key);
+    }
+    if ((size_t)(1 + c->fast_lanes * c->fast_waves) * 4096 > 160 * 1024)
+        return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %d chains exceed the 160 KiB LDS (max 39)",
+                    c->fast_lanes * c->fast_waves);
+    return SNK_OK;
+}
+
+int snk_num_sequences(const snk_ctx *c) { return c ? c->n : SNK_E_ARG; }
+int snk_num_packed(const snk_ctx *c) { return c ? c->n_packed : SNK_E_ARG; }
+
+int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens)
+{
+    if (!c || n_seq < 0 || (n_seq > 0 && (!seqs || !lens))) return fail(c, SNK_E_ARG, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_sequences(c);
+    if (n_seq == 0) return SNK_OK;
+
+    const size_t n = (size_t)n_seq;
+    std::vector<size_t> boff(n), poff(n);
+    size_t btot = SNK_PAD, ptot = SNK_PAD;
+    for (size_t g = 0; g < n; ++g) {
+        if (lens[g] >= 0x7E000000ull) return fail(c, SNK_E_TOOBIG, "sequence %zu too long (%llu B)", g, (unsigned long long)lens[g]);
+        if (lens[g] && !seqs[g]) return fail(c, SNK_E_ARG, "sequence %zu is NULL", g);
+        boff[g] = btot; btot += ((size_t)lens[g] + 63) / 64 * 64 + SNK_PAD;
+    }
+    c->len.resize(n);
+    for (size_t g = 0; g < n; ++g) c->len[g] = (uint32_t)lens[g];
+
+    HIPCHK(c, hipMalloc((void **)&c->d_bytes, btot));
+    HIPCHK(c, hipMemsetAsync(c->d_bytes, 0, btot, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t g = 0; g < n; ++g)
+        if (lens[g]) HIPCHK(c, hipMemcpy(c->d_bytes + boff[g], seqs[g], lens[g], hipMemcpyHostToDevice));
+
+    // ---- classify -------------------------------------------------------------------------
+    uint32_t *d_flags = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_flags, n * sizeof(uint32_t)));
+    {
+        std::vector<uint32_t> ones(n, 1u);
+        HIPCHK(c, hipMemcpy(d_flags, ones.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    for (size_t g = 0; g < n; ++g) {
+        if (!lens[g]) continue;
+        uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 1024);
+        hipLaunchKernelGGL(snk_classify_kernel, dim3(grid), dim3(256), 0, c->stream,
+                           c->d_bytes + boff[g], (uint64_t)lens[g], d_flags + g);
+    }
+    std::vector<uint32_t> flags(n);
+    HIPCHK(c, hipMemcpyAsync(flags.data(), d_flags, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(d_flags);
+
+    // ---- pack pure-ACGT sequences ------------------------------------------------------------
+    c->is_packed.assign(n, 0);
+    for (size_t g = 0; g < n; ++g) {
+        c->is_packed[g] = (flags[g] & 1u) && lens[g] > 0;
+        if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
+    }
+    HIPCHK(c, hipMalloc((void **)&c->d_packed, ptot));
+    HIPCHK(c, hipMemsetAsync(c->d_packed, 0, ptot, c->stream));
+    for (size_t g = 0; g < n; ++g) {
+        if (!c->is_packed[g]) continue;
+        uint64_t nb = ((uint64_t)lens[g] + 3) / 4;
+        uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 2048);
+        hipLaunchKernelGGL(snk_pack_kernel, dim3(grid), dim3(256), 0, c->stream,
+                           c->d_bytes + boff[g], (uint64_t)lens[g], c->d_packed + poff[g]);
+    }
+    HIPCHK(c, hipGetLastError());
+
+    // ---- per-sequence tables ------------------------------------------------------------------
+    std::vector<const uint8_t *> bp(n), pp(n);
+    std::vector<uint32_t> spos(n);
+    for (size_t g = 0; g < n; ++g) {
+        bp[g] = c->d_bytes + boff[g];
+        pp[g] = c->is_packed[g] ? c->d_packed + poff[g] : nullptr;
+        spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
+    }
+    HIPCHK(c, hipMalloc((void **)&c->d_bytes_ptr, n * sizeof(void *)));
+    HIPCHK(c, hipMalloc((void **)&c->d_packed_ptr, n * sizeof(void *)));
+    HIPCHK(c, hipMalloc((void **)&c->d_len, n * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap_pos, n * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap_out, n * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_single, n * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap_fast, n * 1024 * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap_gen, n * 4096 * 4));
+    HIPCHK(c, hipMemcpy(c->d_bytes_ptr, bp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_packed_ptr, pp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_len, c->len.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_snap_pos, spos.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync(c->d_snap_out, 0, n * 4, c->stream));
+    c->n = n_seq;
+
+    // ---- singles + snapshots (phase A) --------------------------------------------------------
+    std::vector<SnkJob> fast, gen;
+    std::vector<uint32_t> conv;
+    for (size_t g = 0; g < n; ++g) {
+        SnkJob jb; jb.xi = (int)g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
+        const bool f = !c->force_generic && c->is_packed[g] && lens[g] > SNK_BLOCK;
+        (f ? fast : gen).push_back(jb);
+        if (f) conv.push_back((uint32_t)g);
+    }
+    const size_t nf = fast.size(), ng = gen.size();
+    c->h_jobs = fast;
+    c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
+    int rc = ensure_scratch(c, n, 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), n * sizeof(SnkJob), hipMemcpyHostToDevice, c->stream));
+    rc = launch_jobs(c, c->stream, c->d_jobs, nf, ng, c->d_single);
+    if (rc) return rc;
+    if (!conv.empty()) {
+        uint32_t *d_ids = nullptr;
+        HIPCHK(c, hipMalloc((void **)&d_ids, conv.size() * 4));
+        HIPCHK(c, hipMemcpyAsync(d_ids, conv.data(), conv.size() * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(snk_snap_convert_kernel, dim3((uint32_t)conv.size()), dim3(256), 0, c->stream,
+                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, d_ids, (uint32_t)conv.size());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dfree(d_ids);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    if (rc) return rc;
+    c->singles_done = true;
+    return SNK_OK;
+}
+
+int snk_singles(snk_ctx *c, uint32_t *sizes)
+{
+    if (!c || (!sizes && c->n)) return fail(c, SNK_E_ARG, "bad arguments");
+    if (!c->singles_done && c->n) return fail(c, SNK_E_STATE, "snk_upload has not completed");
+    if (!c->n) return SNK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(sizes, c->d_single, (size_t)c->n * 4, hipMemcpyDeviceToHost));
+    return SNK_OK;
+}
+
+int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream)
+{
+    if (!c) return SNK_E_ARG;
+    if (!c->singles_done) return fail(c, SNK_E_STATE, "snk_upload has not completed");
+    if (r0 < 0 || r1 < r0 || r1 > c->n || (!d_sizes && r1 > r0)) return fail(c, SNK_E_ARG, "bad row range [%d,%d)", r0, r1);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t N = (size_t)c->n, np = (size_t)(r1 - r0) * N;
+    if (!np) return SNK_OK;
+    size_t nf = 0, ng = 0;
+    // order: suffix j outer, prefix i inner => the chains of a workgroup share seq_j
+    int rc = build_jobs(c, np, [&](size_t t, int &i, int &j, uint32_t &o) {
+        j = (int)(t / (size_t)(r1 - r0)); i = r0 + (int)(t % (size_t)(r1 - r0));
+        o = (uint32_t)((size_t)(i - r0) * N + (size_t)j);
+    }, nf, ng);
+    if (rc) return rc;
+    rc = ensure_scratch(c, np, 0);
+    if (rc) return rc;
+    return run_pairs(c, st, nf, ng, (uint32_t *)d_sizes);
+}
+
+int snk_sync(snk_ctx *c, void *hip_stream)
+{
+    if (!c) return SNK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : c->stream));
+    return check_status(c);
+}
+
+int snk_pairs(snk_ctx *c, int r0, int r1, uint32_t *sizes)
+{
+    if (!c) return SNK_E_ARG;
+    if (r0 < 0 || r1 < r0 || r1 > c->n || (!sizes && r1 > r0)) return fail(c, SNK_E_ARG, "bad row range [%d,%d)", r0, r1);
+    const size_t np = (size_t)(r1 - r0) * (size_t)c->n;
+    if (!np) return SNK_OK;
+    int rc = ensure_scratch(c, 0, np);
+    if (rc) return rc;
+    rc = snk_pairs_device(c, r0, r1, c->d_out, nullptr);
+    if (rc) return rc;
+    rc = snk_sync(c, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(sizes, c->d_out, np * 4, hipMemcpyDeviceToHost));
+    return SNK_OK;
+}
+
+int snk_pairs_list(snk_ctx *c, int n_pairs, const int32_t *ij, uint32_t *sizes)
+{
+    if (!c || n_pairs < 0 || (n_pairs && (!ij || !sizes))) return fail(c, SNK_E_ARG, "bad arguments");
+    if (!c->singles_done) return fail(c, SNK_E_STATE, "snk_upload has not completed");
+    if (!n_pairs) return SNK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t nf = 0, ng = 0;
+    // sort by suffix for locality, keep the caller's output order
+    std::vector<uint32_t> order((size_t)n_pairs);
+    for (uint32_t t = 0; t < (uint32_t)n_pairs; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ij[2 * a + 1] < ij[2 * b + 1]; });
+    int rc = build_jobs(c, (size_t)n_pairs, [&](size_t t, int &i, int &j, uint32_t &o) {
+        o = order[t]; i = ij[2 * o]; j = ij[2 * o + 1];
+    }, nf, ng);
+    if (rc) return rc;
+    rc = ensure_scratch(c, (size_t)n_pairs, (size_t)n_pairs);
+    if (rc) return rc;
+    rc = run_pairs(c, c->stream, nf, ng, c->d_out);
+    if (rc) return rc;
+    rc = snk_sync(c, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(sizes, c->d_out, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    return SNK_OK;
+}
+
+double snk_last_pairs_ms(snk_ctx *c)
+{
+    if (!c || !c->ev_valid) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+} // extern "C"

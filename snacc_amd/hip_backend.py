@@ -1,0 +1,187 @@
+"""ctypes binding to ``libsnacc_hip.so`` (C-ABI in ``include/snacc_hip.h``).
+
+This is the product path for ``-c lz4``: it replaces the per-item
+``lz4framed.compress`` calls of ref:snacc/pairwise_ncd.py:80 with batched HIP
+kernels on an MI355X.  There is deliberately no CPU fallback: if the shared
+library is missing or no GPU is visible, every entry point raises
+:class:`HipBackendError`.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnacc_hip.so")
+ABI_VERSION = 1
+
+#: every symbol ``include/snacc_hip.h`` declares (checked by the CPU test-suite)
+EXPORTS = (
+    "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
+    "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_singles", "snk_pairs",
+    "snk_pairs_device", "snk_pairs_list", "snk_sync", "snk_last_pairs_ms",
+)
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("snacc_hip.hip", "snk_device.hip.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "snacc_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", src_dir])
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and declare signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipBackendError(
+            f"{LIB_PATH} not found: build it with `make -C snacc_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "The lz4 path has no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise HipBackendError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, u32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    L.snk_version.restype = i32
+    L.snk_version.argtypes = []
+    L.snk_last_error.restype = ctypes.c_char_p
+    L.snk_last_error.argtypes = [vp]
+    L.snk_ctx_create.restype = i32
+    L.snk_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.snk_ctx_destroy.restype = None
+    L.snk_ctx_destroy.argtypes = [vp]
+    L.snk_set_option.restype = i32
+    L.snk_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
+    L.snk_upload.restype = i32
+    L.snk_upload.argtypes = [vp, i32, vp, vp]
+    L.snk_num_sequences.restype = i32
+    L.snk_num_sequences.argtypes = [vp]
+    L.snk_num_packed.restype = i32
+    L.snk_num_packed.argtypes = [vp]
+    L.snk_singles.restype = i32
+    L.snk_singles.argtypes = [vp, u32p]
+    L.snk_pairs.restype = i32
+    L.snk_pairs.argtypes = [vp, i32, i32, u32p]
+    L.snk_pairs_device.restype = i32
+    L.snk_pairs_device.argtypes = [vp, i32, i32, vp, vp]
+    L.snk_pairs_list.restype = i32
+    L.snk_pairs_list.argtypes = [vp, i32, vp, u32p]
+    L.snk_sync.restype = i32
+    L.snk_sync.argtypes = [vp, vp]
+    L.snk_last_pairs_ms.restype = ctypes.c_double
+    L.snk_last_pairs_ms.argtypes = [vp]
+    if L.snk_version() != ABI_VERSION:
+        raise HipBackendError(f"ABI mismatch: library {L.snk_version()}, binding {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def _as_u8(seq):
+    if isinstance(seq, np.ndarray):
+        return np.ascontiguousarray(seq, dtype=np.uint8)
+    if isinstance(seq, str):
+        seq = seq.encode("utf-8")  # ref:snacc/pairwise_ncd.py:69  bytes(sequence, encoding="utf-8")
+    return np.frombuffer(seq, dtype=np.uint8)
+
+
+class HipContext:
+    """One device context (one per process / GPU).  Not thread-safe."""
+
+    def __init__(self, device=0, **options):
+        self._L = load()
+        h = ctypes.c_void_p()
+        rc = self._L.snk_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise HipBackendError(f"snk_ctx_create({device}) failed [{rc}]: "
+                                  f"{self._L.snk_last_error(None).decode()}")
+        self._h = h
+        self.device = int(device)
+        self.n = 0
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    # -- plumbing -----------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HipBackendError(f"{what} failed [{rc}]: {self._L.snk_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.snk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, key, value):
+        self._check(self._L.snk_set_option(self._h, key.encode(), int(value)), f"snk_set_option({key})")
+
+    # -- data ---------------------------------------------------------------------------
+    def upload(self, sequences):
+        """sequences: iterable of bytes / str / uint8 arrays (the extracted residues per file)."""
+        arrs = [_as_u8(s) for s in sequences]
+        n = len(arrs)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (ctypes.c_uint64 * max(n, 1))(*[a.size for a in arrs])
+        self._check(self._L.snk_upload(self._h, n, ptrs, lens), "snk_upload")
+        self.n = n
+        return self
+
+    @property
+    def num_packed(self):
+        return self._L.snk_num_packed(self._h)
+
+    # -- phase A / B --------------------------------------------------------------------
+    def singles(self):
+        out = np.zeros(self.n, dtype=np.uint32)
+        self._check(self._L.snk_singles(self._h, out.ctypes.data), "snk_singles")
+        return out
+
+    def pairs(self, row_begin=0, row_end=None):
+        row_end = self.n if row_end is None else row_end
+        out = np.zeros((max(row_end - row_begin, 0), self.n), dtype=np.uint32)
+        self._check(self._L.snk_pairs(self._h, row_begin, row_end, out.ctypes.data), "snk_pairs")
+        return out
+
+    def pairs_device(self, row_begin, row_end, d_ptr, stream=None):
+        """Async launch; writes (row_end-row_begin)*n uint32 at device address ``d_ptr``."""
+        self._check(self._L.snk_pairs_device(self._h, row_begin, row_end, ctypes.c_void_p(d_ptr),
+                                             ctypes.c_void_p(stream) if stream else None),
+                    "snk_pairs_device")
+
+    def pairs_list(self, ij):
+        ij = np.ascontiguousarray(ij, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros(len(ij), dtype=np.uint32)
+        self._check(self._L.snk_pairs_list(self._h, len(ij), ij.ctypes.data, out.ctypes.data), "snk_pairs_list")
+        return out
+
+    def sync(self, stream=None):
+        self._check(self._L.snk_sync(self._h, ctypes.c_void_p(stream) if stream else None), "snk_sync")
+
+    def last_pairs_ms(self):
+        return float(self._L.snk_last_pairs_ms(self._h))
