@@ -25,7 +25,7 @@ struct snk_ctx_impl {
     std::string err;
 
     // options
-    int fast_lanes = 9, fast_waves = 4, gen_chains = 8;
+    int fast_lanes = 21, fast_waves = 4, gen_chains = 8;
     bool force_generic = false;
     uint32_t header_bytes = 7;
 
@@ -37,7 +37,7 @@ struct snk_ctx_impl {
     const uint8_t **d_bytes_ptr = nullptr, **d_packed_ptr = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
-    uint32_t *d_lut_partner = nullptr, *d_lut_hash = nullptr;
+    uint16_t *d_lut_slot = nullptr; uint32_t *d_lut_hash = nullptr;
     uint32_t *d_single = nullptr, *d_status = nullptr;
     bool singles_done = false;
 
@@ -87,25 +87,19 @@ uint32_t host_hash5(const uint8_t *p)
     return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
 }
 
-bool build_luts(std::vector<uint32_t> &partner, std::vector<uint32_t> &hash)
+bool build_luts(std::vector<uint16_t> &slot, std::vector<uint32_t> &hash)
 {
-    partner.assign(1024, 0); hash.assign(1024, 0);
-    std::vector<std::vector<uint32_t>> cls(4096);
+    slot.assign(1024, 0); hash.assign(1024, 0);
+    std::vector<int> slot_of_hash(4096, -1);
+    int n_slots = 0;
     for (uint32_t k = 0; k < 1024; ++k) {
         uint8_t b[5];
         for (int i = 0; i < 5; ++i) b[i] = (uint8_t)kCodeToByte[(k >> (2 * i)) & 3];
         hash[k] = host_hash5(b);
-        cls[hash[k]].push_back(k);
+        if (slot_of_hash[hash[k]] < 0) slot_of_hash[hash[k]] = n_slots++;
+        slot[k] = (uint16_t)slot_of_hash[hash[k]];
     }
-    for (uint32_t k = 0; k < 1024; ++k) {
-        const auto &m = cls[hash[k]];
-        if (m.size() > 4) return false;              // would not fit 3 partners (never for this hash)
-        uint32_t p[3] = { k, k, k };
-        int t = 0;
-        for (uint32_t o : m) if (o != k) p[t++] = o;
-        partner[k] = p[0] | (p[1] << 10) | (p[2] << 20);
-    }
-    return true;
+    return n_slots <= (int)SNK_FSLOTS;               // 894 for liblz4's hash5
 }
 
 SnkTables make_tables(const snk_ctx_impl *c)
@@ -114,7 +108,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.bytes = c->d_bytes_ptr; T.packed = c->d_packed_ptr; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
-    T.lut_partner = c->d_lut_partner; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
+    T.lut_slot = c->d_lut_slot; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
 
@@ -142,7 +136,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     if (n_fast) {
         const uint32_t lanes = (uint32_t)c->fast_lanes, waves = (uint32_t)c->fast_waves;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)(1 + chains) * 4096;
+        const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
+        if (lds > 160 * 1024)
+            return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", chains);
         HIPCHK(c, hipFuncSetAttribute((const void *)snk_fast_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
@@ -260,15 +256,15 @@ int snk_ctx_create(int device, snk_ctx **out)
     CRCHK(hipMalloc((void **)&c->d_zero, 4 * SNK_PAD));
     CRCHK(hipMemset(c->d_zero, 0, 4 * SNK_PAD));
     {
-        std::vector<uint32_t> partner, hash;
-        if (!build_luts(partner, hash)) {
-            fail(nullptr, SNK_E_STATE, "5-mer collision class larger than 4");
+        std::vector<uint16_t> slot; std::vector<uint32_t> hash;
+        if (!build_luts(slot, hash)) {
+            fail(nullptr, SNK_E_STATE, "5-mer slot count exceeds the table");
             snk_ctx_destroy(c);
             return SNK_E_STATE;
         }
-        CRCHK(hipMalloc((void **)&c->d_lut_partner, 1024 * sizeof(uint32_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_slot, 1024 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_hash, 1024 * sizeof(uint32_t)));
-        CRCHK(hipMemcpy(c->d_lut_partner, partner.data(), 4096, hipMemcpyHostToDevice));
+        CRCHK(hipMemcpy(c->d_lut_slot, slot.data(), 2048, hipMemcpyHostToDevice));
         CRCHK(hipMemcpy(c->d_lut_hash, hash.data(), 4096, hipMemcpyHostToDevice));
     }
 #undef CRCHK
@@ -282,7 +278,7 @@ void snk_ctx_destroy(snk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_sequences(c);
-    dfree(c->d_zero); dfree(c->d_lut_partner); dfree(c->d_lut_hash); dfree(c->d_status);
+    dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -311,9 +307,6 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else {
         return fail(c, SNK_E_ARG, "unknown option '%s'", key);
     }
-    if ((size_t)(1 + c->fast_lanes * c->fast_waves) * 4096 > 160 * 1024)
-        return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %d chains exceed the 160 KiB LDS (max 39)",
-                    c->fast_lanes * c->fast_waves);
     return SNK_OK;
 }
 
@@ -394,7 +387,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipMalloc((void **)&c->d_snap_pos, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_out, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_single, n * 4));
-    HIPCHK(c, hipMalloc((void **)&c->d_snap_fast, n * 1024 * 4));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap_fast, n * SNK_FSLOTS * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_gen, n * 4096 * 4));
     HIPCHK(c, hipMemcpy(c->d_bytes_ptr, bp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_packed_ptr, pp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
@@ -425,7 +418,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         HIPCHK(c, hipMalloc((void **)&d_ids, conv.size() * 4));
         HIPCHK(c, hipMemcpyAsync(d_ids, conv.data(), conv.size() * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(snk_snap_convert_kernel, dim3((uint32_t)conv.size()), dim3(256), 0, c->stream,
-                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, d_ids, (uint32_t)conv.size());
+                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, c->d_lut_slot, d_ids, (uint32_t)conv.size());
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         dfree(d_ids);

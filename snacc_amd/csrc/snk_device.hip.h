@@ -48,9 +48,9 @@ struct SnkTables {
     const uint32_t *len;
     const uint32_t *snap_pos;         // block-aligned prefix length covered by the snapshot (0 = none)
     uint32_t       *snap_out;         // frame bytes (header included) after snap_pos
-    uint32_t       *snap_fast;        // [n][1024] 5-mer indexed tables (ACGT sequences)
+    uint32_t       *snap_fast;        // [n][896] slot indexed tables (ACGT sequences), absolute positions
     uint32_t       *snap_gen;         // [n][4096] hash indexed tables
-    const uint32_t *lut_partner;      // [1024]  3 x 10-bit colliding 5-mer codes (self when none)
+    const uint16_t *lut_slot;         // [1024]  5-mer code -> table slot (0..893); colliding 5-mers share one
     const uint8_t  *zero_pad;         // >= 2*SNK_PAD zero bytes
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };
@@ -70,67 +70,208 @@ __device__ __forceinline__ uint32_t snk_lit_ext(uint32_t lit)
 // =========================================================================
 //  2-bit ACGT kernel
 // =========================================================================
+//
+// LDS per chain (1904 B): tbl[896] u16 + bm[28] u32.
+//   liblz4's table maps a 12-bit hash slot to the last inserted absolute position
+//   and rejects candidates further than 65535 back.  Pure-ACGT input reaches only
+//   894 slots (1024 5-mers, colliding ones share a slot: LUT `slot[5-mer]`).
+//   Positions are kept as 16-bit offsets inside their 64 KiB frame block, with one
+//   bit per slot saying "written during the current block":
+//     bit set            -> candidate = block_base + off            (distance < 64 Ki)
+//     bit clear, off > c -> candidate = block_base - 65536 + off    (previous block,
+//                           distance = 65536 + c - off <= 65535 exactly when off > c)
+//     otherwise          -> too far / never written (off 0 is never > c)
+//   At every block transition entries whose bit is clear (older than one block)
+//   are zeroed and the bitmap is cleared: exactly liblz4's "too far" rule.
+#define SNK_FSLOTS      896u                    // 894 used, padded to a multiple of 32
+#define SNK_FBMWORDS    28u
+#define SNK_FCHAIN_B    (SNK_FSLOTS * 2u + SNK_FBMWORDS * 4u)      // 1904 bytes
+#define SNK_FLUT_B      2048u                   // slot LUT: 1024 x u16
+
+// global-memory (address space 1) pointers keep hipcc on global_load_* instead of flat_load_*
+typedef __attribute__((address_space(1))) const uint8_t snk_g8;
+struct __attribute__((packed)) SnkU64 { uint64_t v; };
+struct __attribute__((packed)) SnkU32 { uint32_t v; };
+__device__ __forceinline__ uint64_t snk_ld8g(snk_g8 *p)
+{
+    return ((__attribute__((address_space(1))) const SnkU64 *)p)->v;   // byte-aligned 8-byte load
+}
+__device__ __forceinline__ uint32_t snk_ld4g(snk_g8 *p)
+{
+    return ((__attribute__((address_space(1))) const SnkU32 *)p)->v;   // byte-aligned 4-byte load
+}
 
 struct SnkFastSrc {
-    const uint8_t *xp, *yp;   // packed; base i of a sequence at bits 2(i&3) of byte i>>2
+    snk_g8 *xp, *yp;          // packed; base i of a sequence at bits 2(i&3) of byte i>>2
     uint32_t lx;
 };
 
-// 64-bit window over the virtual concatenation x+y: bases [p-8, p+21) with
-// base p-8 at bit 0 (29 bases valid, top 6 bits zero).
-__device__ __forceinline__ uint64_t snk_fetchw_straddle(const SnkFastSrc &s, uint32_t p)
+// 32-bit window over the virtual concatenation x+y: the 16 bases [p-4, p+12),
+// base p-4 at bits 0..1.  5-mer at p = bits 8..17, 5-mer at p-2 = bits 4..13.
+__device__ __forceinline__ uint32_t snk_w32_at(snk_g8 *b, int32_t q)
 {
-    int32_t q = (int32_t)p - 8;                         // q < lx < q + 29
-    uint64_t xv = snk_ld8u(s.xp + (q >> 2)) >> ((q & 3) * 2);   // zero beyond lx (padding)
-    uint32_t sh = 2u * (uint32_t)((int32_t)s.lx - q);   // 2..56
-    uint64_t yv = snk_ld8u(s.yp) << sh;
-    return (xv | yv) & 0x03FFFFFFFFFFFFFFull;
+    const uint64_t v = snk_ld8g(b + (q >> 2));
+    return __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, (uint32_t)(q & 3) * 2u);
 }
 
-__device__ __forceinline__ uint64_t snk_fetchw(const SnkFastSrc &s, uint32_t p)
+__device__ __forceinline__ uint32_t snk_fetch32(const SnkFastSrc &s, uint32_t p)
 {
-    int32_t q0 = (int32_t)p - 8;
-    bool inx = (p + 21u <= s.lx);
-    bool iny = (q0 >= (int32_t)s.lx);
+    const int32_t q0 = (int32_t)p - 4;
+    const bool inx = (p + 12u <= s.lx);
+    const bool iny = (q0 >= (int32_t)s.lx);
     if (__builtin_expect(inx | iny, 1)) {
-        int32_t q = iny ? q0 - (int32_t)s.lx : q0;
-        const uint8_t *b = iny ? s.yp : s.xp;
-        return snk_ld8u(b + (q >> 2)) >> ((q & 3) * 2);
+        const int32_t q = iny ? q0 - (int32_t)s.lx : q0;
+        return snk_w32_at(iny ? s.yp : s.xp, q);
     }
-    return snk_fetchw_straddle(s, p);
+    // seam: q0 < lx < q0 + 16.  x is zero padded beyond lx.
+    const uint32_t xv = snk_w32_at(s.xp, q0);
+    const uint32_t sh = 2u * (uint32_t)((int32_t)s.lx - q0);        // 2..30
+    return xv | ((uint32_t)snk_ld8g(s.yp) << sh);
 }
 
 __device__ __forceinline__ uint32_t snk_base_at(const SnkFastSrc &s, uint32_t p)
 {
-    return (uint32_t)snk_fetchw(s, p + 8u) & 3u;
+    return snk_fetch32(s, p + 4u) & 3u;
 }
 
-// put(): table[k] = pos, plus the 5-mers that share k's slot in liblz4's hash
-__device__ __forceinline__ void snk_fast_put(uint32_t *tbl, uint32_t k, uint32_t pk, uint32_t pos)
+// Cursor-side reservoir: 32 packed bases [rb, rb+32) of ONE source sequence in
+// registers (r0, r1) plus the next 16 (nx) already in flight, so the window at the
+// probe position costs no memory latency.  (rb - org) % 4 == 0.
+struct SnkWin {
+    snk_g8 *src;
+    uint32_t org;      // stream position of base 0 of src (0 for x, lx for y)
+    uint32_t rb;       // stream position of bit 0 of r0
+    uint32_t lim;      // largest probe position this source can serve
+    uint32_t r0, r1, nx;
+};
+
+__device__ __forceinline__ void snk_win_init(SnkWin &w, snk_g8 *src, uint32_t org, uint32_t lim, uint32_t cur)
 {
-    tbl[k] = pos;
-    uint32_t p1 = pk & 1023u, p2 = (pk >> 10) & 1023u, p3 = (pk >> 20) & 1023u;
-    if (p1 != k) {
-        tbl[p1] = pos;
-        if (p2 != k) {
-            tbl[p2] = pos;
-            if (p3 != k) tbl[p3] = pos;
+    w.src = src; w.org = org; w.lim = lim;
+    w.rb = org + ((cur - 4u - org) & ~3u);
+    snk_g8 *p = src + ((w.rb - org) >> 2);
+    w.r0 = snk_ld4g(p); w.r1 = snk_ld4g(p + 4); w.nx = snk_ld4g(p + 8);
+}
+
+struct SnkFastState {
+    uint32_t cur, step, nb, anchor, op;
+    uint32_t mfl1, mlimit, olimit, base;   // base = stream position of the block start
+    bool pending;
+};
+
+// One probe of the flat parse loop.  Returns 0 = continue, 1 = block ends with
+// last-literals, 2 = liblz4 gives up on the block (stored raw).
+// YONLY: wave-uniform promise that every lane's cursor is > 64 KiB + 4 past the
+// seam, so cursor and candidate windows both come from y.
+template <bool YONLY>
+__device__ __forceinline__ int snk_fast_probe(SnkFastState &st, SnkWin &w, const SnkFastSrc &s,
+                                              uint16_t *tbl, uint32_t *bm, const uint16_t *slot)
+{
+    const uint32_t cur = st.cur;
+    const uint32_t next = cur + st.step;
+    if (__builtin_expect(next > st.mfl1, 0)) return 1;
+
+    // ---- cursor window from registers ----
+    uint32_t wc;
+    {
+        uint32_t o = cur - 4u - w.rb;                        // need 0 <= o <= 15
+        if ((o - 16u) < 16u) {                               // slide by 16 bases (every ~3 probes)
+            w.r0 = w.r1; w.r1 = w.nx; w.rb += 16u; o -= 16u;
+            w.nx = snk_ld4g(w.src + ((w.rb + 32u - w.org) >> 2));
+        }
+        if (__builtin_expect(o > 15u || cur > w.lim, 0)) {   // long jump / source change / seam
+            if (cur >= s.lx + 4u)                        snk_win_init(w, s.yp, s.lx, 0xFFFFFFFFu, cur);
+            else if (cur >= 4u && cur + 12u <= s.lx)     snk_win_init(w, s.xp, 0u, s.lx - 12u, cur);
+            else                                         w.rb = 0x80000000u;     // slow path
+            o = cur - 4u - w.rb;
+        }
+        if (YONLY || __builtin_expect(o <= 15u, 1)) wc = __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
+        else                                        wc = snk_fetch32(s, cur);
+    }
+    // ---- table probe: two LDS round trips (slot LUT, then table + bitmap) ----
+    const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
+    const uint32_t s2 = slot[(wc >> 4) & 1023u];             // slot of the 5-mer at cur-2
+    const uint32_t e = tbl[s1];
+    const uint32_t bw = bm[s1 >> 5];
+    const uint32_t c = cur - st.base;                        // offset in the block, 1..65535
+    const uint32_t bit1 = 1u << (s1 & 31u);
+    const bool iscur = (bw & bit1) != 0u;
+    uint32_t cand = st.base + e - (iscur ? 0u : 65536u);
+    bool valid = iscur | (e > c);
+    if (st.pending) {
+        // liblz4 puts cur-2 BEFORE it reads the slot of cur: same slot => candidate is cur-2
+        if (s2 == s1) { cand = cur - 2u; valid = true; }
+        tbl[s2] = (uint16_t)(c - 2u);
+        atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+    }
+    tbl[s1] = (uint16_t)c;
+    if (!iscur) atomicOr(&bm[s1 >> 5], bit1);
+    { const uint32_t s3 = st.nb >> 6; st.step = s3 ? s3 : 1u; st.nb++; }
+    cand = valid ? cand : cur;                               // keep the fetch in bounds
+
+    // ---- candidate window: the one global-memory round trip of the probe ----
+    const uint32_t wd = YONLY ? snk_w32_at(s.yp, (int32_t)(cand - 4u - s.lx)) : snk_fetch32(s, cand);
+    const uint32_t x = wc ^ wd;
+    uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;   // equal bases from cur, 0..12
+    if (!(valid && f >= 4u)) { st.cur = next; st.pending = false; return 0; }
+
+    // ---------------- match ----------------
+    uint32_t ip = cur;
+    uint32_t lit = cur - st.anchor;
+    if (lit != 0u && cand != 0u) {                           // catch up (search-found matches only)
+        const uint32_t t = x & 0xFFu;
+        const uint32_t eq = t ? ((uint32_t)__builtin_clz(t << 24) >> 1) : 4u;
+        uint32_t b = eq < lit ? eq : lit;
+        b = b < cand ? b : cand;
+        ip -= b; cand -= b; lit -= b;
+        if (__builtin_expect(b == 4u, 0)) {
+            while (ip > st.anchor && cand > 0u &&
+                   snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
         }
     }
+    uint32_t e2 = cur + f;
+    if (__builtin_expect(f == 12u, 0)) {                     // long match: keep counting, 16 bases a time
+        uint32_t bpos = cand + (cur - ip) + 12u;
+        while (e2 < st.mlimit) {
+            const uint32_t d = snk_fetch32(s, e2 + 4u) ^ snk_fetch32(s, bpos + 4u);
+            const uint32_t cnt = d ? ((uint32_t)__builtin_ctz(d) >> 1) : 16u;
+            e2 += cnt; bpos += cnt;
+            if (cnt < 16u) break;
+        }
+    }
+    if (e2 > st.mlimit) e2 = st.mlimit;
+    const uint32_t mc = e2 - ip - 4u;
+    if (__builtin_expect(lit < 15u && mc < 15u, 1)) {
+        // both limitedOutput checks of liblz4 reduce to the same inequality here
+        if (__builtin_expect(st.op + lit + 9u > st.olimit, 0)) return 2;
+        st.op += lit + 3u;
+    } else {
+        uint32_t op = st.op + 1u;
+        if (op + lit + 8u + lit / 255u > st.olimit) return 2;
+        op += lit + snk_lit_ext(lit) + 2u;
+        if (op + 6u + (mc + 240u) / 255u > st.olimit) return 2;
+        if (mc >= 15u) op += (mc - 15u) / 255u + 1u;
+        st.op = op;
+    }
+    st.anchor = e2;
+    st.cur = e2; st.step = 1u; st.nb = 63u; st.pending = true;
+    return e2 >= st.mfl1 ? 1 : 0;
 }
 
-// One chain of the 2-bit kernel.  `tbl` = this chain's 1024 x u32 LDS table,
-// `lut` = the workgroup's partner LUT in LDS.
+// One chain of the 2-bit kernel.  `lds` = this chain's 1904 bytes, `slot` = the
+// workgroup's 5-mer -> slot LUT.
 __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob job,
-                                               uint32_t *tbl, const uint32_t *lut,
+                                               uint8_t *lds, const uint16_t *slot,
                                                uint32_t *out, uint32_t *status)
 {
+    uint16_t *tbl = (uint16_t *)lds;
+    uint32_t *bm = (uint32_t *)(lds + SNK_FSLOTS * 2u);
     SnkFastSrc s;
     const uint32_t lx = T.len[job.xi];
     const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
     const uint32_t n = lx + ly;
-    s.xp = T.packed[job.xi];
-    s.yp = job.yi >= 0 ? T.packed[job.yi] : T.zero_pad + SNK_PAD;
+    s.xp = (snk_g8 *)T.packed[job.xi];
+    s.yp = (snk_g8 *)(job.yi >= 0 ? T.packed[job.yi] : T.zero_pad + SNK_PAD);
     s.lx = lx;
 
     uint32_t pos, total;
@@ -138,19 +279,24 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
     if (job.snap == 0 && spos != 0u) { pos = spos; total = T.snap_out[job.xi]; }
     else                             { pos = 0u;   total = T.header_bytes; }
 
-    // per-block state
-    uint32_t cur = 0, step = 1, nb = 64, anchor = 0, op = 0;
-    uint32_t iend = 0, mfl1 = 0, mlimit = 0, olimit = 0, blen = 0;
-    bool pending = false;       // put(ip-2) owed before the next probe
-    bool in_block = false;
-    uint64_t guard = 2ull * n + 4096ull;
+    SnkFastState st;
+    st.cur = 0; st.step = 1; st.nb = 64; st.anchor = 0; st.op = 0;
+    st.mfl1 = 0; st.mlimit = 0; st.olimit = 0; st.base = pos; st.pending = false;
+    uint32_t iend = 0, blen = 0;
+    bool in_block = false, first = true;
+    uint32_t guard = n + (n >> 10) + 4096u;     // every iteration advances cur or ends a block
+
+    SnkWin w;
+    w.src = s.xp; w.org = 0u; w.rb = 0x80000000u; w.lim = 0u; w.r0 = w.r1 = w.nx = 0u;
 
     for (;;) {
         if (!in_block) {
             // ---------------- block transition (once per 64 KiB) ----------------
             if (job.snap != 0 && pos == spos && spos != 0u) {
-                uint32_t *dst = T.snap_fast + (size_t)job.xi * 1024u;
-                for (uint32_t t = 0; t < 1024u; ++t) dst[t] = tbl[t];
+                // prefix snapshot: absolute positions; entries older than one block -> 0 (too far for good)
+                uint32_t *dst = T.snap_fast + (size_t)job.xi * SNK_FSLOTS;
+                for (uint32_t t = 0; t < SNK_FSLOTS; ++t)
+                    dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (pos - 65536u + tbl[t]) : 0u;
                 T.snap_out[job.xi] = total;
             }
             if (pos >= n) break;
@@ -161,88 +307,43 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
                 pos = iend;
                 continue;
             }
-            mfl1 = iend - 11u; mlimit = iend - 5u; olimit = blen - 1u;
+            if (!first) {
+                // age the table: entries not written during the block just finished are dead
+                for (uint32_t wi = 0; wi < SNK_FBMWORDS; ++wi) {
+                    uint32_t z = ~bm[wi];
+                    while (z) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(z);
+                        tbl[wi * 32u + b] = 0;
+                        z &= z - 1u;
+                    }
+                    bm[wi] = 0u;
+                }
+            }
+            first = false;
+            st.base = pos;
+            st.mfl1 = iend - 11u; st.mlimit = iend - 5u; st.olimit = blen - 1u;
             {
-                uint64_t w = snk_fetchw(s, pos);
-                uint32_t k = (uint32_t)(w >> 16) & 1023u;
-                snk_fast_put(tbl, k, lut[k], pos);
+                const uint32_t w0 = snk_fetch32(s, pos);
+                const uint32_t s0 = slot[(w0 >> 8) & 1023u];
+                tbl[s0] = 0;                                          // offset 0 of this block
+                atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
             }
-            cur = pos + 1u; step = 1u; nb = 64u; anchor = pos; op = 0u;
-            pending = false; in_block = true;
+            st.cur = pos + 1u; st.step = 1u; st.nb = 64u; st.anchor = pos; st.op = 0u;
+            st.pending = false; in_block = true;
         }
-        if (--guard == 0) { atomicOr(status, SNK_ST_ITERCAP); break; }
+        if (--guard == 0u) { atomicOr(status, SNK_ST_ITERCAP); break; }
 
-        // ---------------- one probe ----------------
-        const uint32_t next = cur + step;
-        bool bail = false, last = false;
-        if (next > mfl1) {
-            last = true;
-        } else {
-            const uint64_t wc = snk_fetchw(s, cur);
-            if (pending) {
-                uint32_t k2 = (uint32_t)(wc >> 12) & 1023u;       // 5-mer at cur-2
-                snk_fast_put(tbl, k2, lut[k2], cur - 2u);
-            }
-            const uint32_t k = (uint32_t)(wc >> 16) & 1023u;       // 5-mer at cur
-            uint32_t cand = tbl[k];
-            snk_fast_put(tbl, k, lut[k], cur);
-            { uint32_t s2 = nb >> 6; step = s2 ? s2 : 1u; nb++; }
+        int r;
+        const bool yonly = st.cur >= lx + 65536u + 8u;
+        if (__all(yonly)) r = snk_fast_probe<true>(st, w, s, tbl, bm, slot);
+        else              r = snk_fast_probe<false>(st, w, s, tbl, bm, slot);
 
-            const uint64_t wd = snk_fetchw(s, cand);
-            const uint64_t x = wc ^ wd;
-            const uint64_t fw = (x >> 16) | (1ull << 42);          // 21 forward bases
-            uint32_t f = (uint32_t)__builtin_ctzll(fw) >> 1;       // equal bases from cur
-            const bool near = cand + SNK_MAXDIST >= cur;
-            if (near && f >= 4u) {
-                // ---------------- match ----------------
-                uint32_t ip = cur;
-                uint32_t lit = ip - anchor;
-                if (lit != 0u && cand != 0u) {                     // catch up
-                    uint32_t t = (uint32_t)x & 0xFFFFu;
-                    uint32_t eq = t ? ((uint32_t)__builtin_clz(t << 16) >> 1) : 8u;
-                    uint32_t b = eq < lit ? eq : lit;
-                    b = b < cand ? b : cand;
-                    ip -= b; cand -= b; lit -= b;
-                    if (b == 8u) {
-                        while (ip > anchor && cand > 0u &&
-                               snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
-                    }
-                }
-                op += 1u;
-                if (op + lit + 8u + lit / 255u > olimit) bail = true;
-                else {
-                    op += lit + snk_lit_ext(lit) + 2u;
-                    uint32_t e = cur + f;
-                    if (f == 21u) {                                // long match: keep counting
-                        uint32_t bpos = cand + (cur - ip) + 21u;
-                        while (e < mlimit) {
-                            uint64_t d = snk_fetchw(s, e + 8u) ^ snk_fetchw(s, bpos + 8u);
-                            uint32_t c = d ? ((uint32_t)__builtin_ctzll(d) >> 1) : 29u;
-                            if (c > 29u) c = 29u;
-                            e += c; bpos += c;
-                            if (c < 29u) break;
-                        }
-                    }
-                    if (e > mlimit) e = mlimit;
-                    const uint32_t mc = e - (ip + 4u);
-                    if (op + 6u + (mc + 240u) / 255u > olimit) bail = true;
-                    else {
-                        if (mc >= 15u) op += (mc - 15u) / 255u + 1u;
-                        anchor = e;
-                        cur = e; step = 1u; nb = 63u; pending = true;
-                        if (e >= mfl1) last = true;
-                    }
-                }
-            } else {
-                cur = next; pending = false;
-            }
-        }
-        if (bail | last) {
+        if (__builtin_expect(r != 0, 0)) {
             uint32_t payload = blen;
-            if (!bail) {
-                uint32_t run = iend - anchor;
-                if (op + run + 1u + (run + 240u) / 255u <= olimit)
-                    payload = op + 1u + snk_lit_ext(run) + run;
+            if (r == 1) {
+                const uint32_t run = iend - st.anchor;
+                if (st.op + run + 1u + (run + 240u) / 255u <= st.olimit)
+                    payload = st.op + 1u + snk_lit_ext(run) + run;
             }
             total += 4u + payload;
             pos = iend;
@@ -252,42 +353,55 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
     out[job.out_idx] = total + 4u;      // end mark
 }
 
-// grid: one workgroup per `lanes*waves` jobs.  dynamic LDS = 4 KiB LUT + 4 KiB per chain.
+// grid: one workgroup per `lanes*waves` jobs.  dynamic LDS = 2 KiB LUT + 1904 B per chain.
 __global__ void snk_fast_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                 uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t snk_lds[];
-    uint32_t *lut = snk_lds;
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    uint16_t *slot = (uint16_t *)snk_lds8;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
     const uint32_t chains = lanes * waves;
 
-    for (uint32_t t = tid; t < 1024u; t += blockDim.x) lut[t] = T.lut_partner[t];
+    for (uint32_t t = tid; t < 512u; t += blockDim.x)
+        ((uint32_t *)slot)[t] = ((const uint32_t *)T.lut_slot)[t];
 
     // chain c of the workgroup -> lane c / waves of wave c % waves  (spreads a
     // partially filled tail group over all waves)
     const uint32_t c = lane * waves + wave;
     const uint32_t j = blockIdx.x * chains + c;
     const bool active = lane < lanes && j < n_jobs;
-    uint32_t *tbl = snk_lds + 1024u + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * 1024u;
+    uint8_t *mine = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * SNK_FCHAIN_B;
 
     SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
     if (active) job = jobs[j];
 
-    // cooperative table initialisation: snapshot of the prefix sequence, or zeros
+    // cooperative table initialisation from the prefix snapshot (or the all-zero start state)
     for (uint32_t l = 0; l < lanes; ++l) {
         const int a   = __shfl((int)active, (int)l);
         const int xi  = __shfl(job.xi, (int)l);
         const int snp = __shfl(job.snap, (int)l);
         if (!a) continue;
-        uint32_t *dst = snk_lds + 1024u + (size_t)(wave * lanes + l) * 1024u;
-        const bool use = (snp == 0) && (T.snap_pos[xi] != 0u);
-        const uint32_t *src = T.snap_fast + (size_t)xi * 1024u;
-        for (uint32_t t = lane; t < 1024u; t += 64u) dst[t] = use ? src[t] : 0u;
+        uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + l) * SNK_FCHAIN_B;
+        const uint32_t spos = T.snap_pos[xi];
+        const bool use = (snp == 0) && (spos != 0u);
+        const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
+        for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += 64u) {
+            uint32_t v = 0u;
+            if (use) {
+                const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
+                const uint32_t lo = (a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u;   // previous block, else dead
+                const uint32_t hi = (a1 + 65536u >= spos) ? (a1 & 0xFFFFu) : 0u;
+                v = lo | (hi << 16);
+            }
+            ((uint32_t *)dst)[t] = v;
+        }
+        // no snapshot: stream start, every slot holds position 0 "written in this block"
+        if (lane < SNK_FBMWORDS) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[lane] = use ? 0u : 0xFFFFFFFFu;
     }
     __syncthreads();
 
-    if (active) snk_fast_chain(T, job, tbl, lut, out, status);
+    if (active) snk_fast_chain(T, job, mine, slot, out, status);
 }
 
 // =========================================================================
@@ -505,15 +619,16 @@ __global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packe
     }
 }
 
-// 5-mer-indexed snapshot -> hash-indexed snapshot (for ACGT prefix + non-ACGT suffix pairs)
+// slot-indexed snapshot -> hash-indexed snapshot (for ACGT prefix + non-ACGT suffix pairs)
 __global__ void snk_snap_convert_kernel(const uint32_t *snap_fast, uint32_t *snap_gen,
-                                        const uint32_t *lut_hash, const uint32_t *seq_ids, uint32_t n_ids)
+                                        const uint32_t *lut_hash, const uint16_t *lut_slot,
+                                        const uint32_t *seq_ids, uint32_t n_ids)
 {
     const uint32_t g = seq_ids[blockIdx.x];
     (void)n_ids;
     uint32_t *dst = snap_gen + (size_t)g * 4096u;
-    const uint32_t *src = snap_fast + (size_t)g * 1024u;
+    const uint32_t *src = snap_fast + (size_t)g * SNK_FSLOTS;
     for (uint32_t t = threadIdx.x; t < 4096u; t += blockDim.x) dst[t] = 0u;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) dst[lut_hash[k]] = src[k];
+    for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) dst[lut_hash[k]] = src[lut_slot[k]];
 }
