@@ -1,0 +1,218 @@
+"""``snacc`` command line (drop-in for ref:snacc/cli.py) with ``-c lz4`` on MI355X.
+
+Flags, prompts, banners, CSV layout and the Markdown run log are the reference's
+(ref:snacc/cli.py:16-68, 138-160, 180-194).  What differs is *how* the sizes are obtained:
+
+* ``-c lz4``: every input file is parsed ONCE, all sequences are uploaded to the GPU and the
+  N + N*N frame sizes come from two batched calls into ``libsnacc_hip.so`` (the reference
+  re-parses both files and calls ``lz4framed.compress`` for each of the N*N tasks,
+  ref:snacc/cli.py:120-129).  Under ``torchrun`` (WORLD_SIZE > 1) the rows are sharded over
+  the ranks and assembled with one RCCL all-gather; rank 0 writes the outputs.
+* other codecs: the reference's own thread-pool flow over ``compressed_size`` (CPU, stdlib).
+"""
+import concurrent.futures
+import itertools
+import os
+import sys
+from datetime import datetime
+from pathlib import Path
+
+import click
+import numpy as np
+import pandas as pd
+from tqdm import tqdm
+
+from .matrix import GETSIZEOF_OVERHEAD, ncd_matrix
+from .pairwise_ncd import compressed_size, compute_distance, extract_sequences
+from .version import __version__
+
+FASTA_SUFFIXES = [".fasta", ".fna", ".fa", ".faa", ".fsa"]
+
+#: stands in for ``lz4framed.__version__`` in the run log (ref:snacc/cli.py:152)
+LZ4_BACKEND_VERSION = f"n/a (snacc_amd {__version__} HIP backend; liblz4 1.9.3 LZ4F_compressFrame semantics)"
+
+
+def discover_files(sequences, fasta=(), directories=()):
+    """Input discovery of ref:snacc/cli.py:90-102: explicit files + FASTA-suffixed entries of the
+    given directories (non-recursive), de-duplicated, sorted by absolute path string."""
+    sequences = [Path(sequence) for sequence in sequences]
+    files = [path for path in sequences if path.is_file()]
+    files.extend([Path(_f) for _f in fasta])
+    sequences.extend([Path(_f) for _f in directories])
+    for directory in [path for path in sequences if path.is_dir()]:
+        for f in directory.iterdir():
+            if f.suffix.lower() in FASTA_SUFFIXES:
+                files.append(f)
+    return sorted(list(set(files)), key=lambda x: str(x.absolute()))
+
+
+def write_matrix_csv(files, matrix, output):
+    """CSV exactly as ``DataFrame.pivot(index='file', columns='file2', values='ncd').to_csv``
+    writes it (ref:snacc/cli.py:138-142): header ``file,<path>...``, one row per file, rows and
+    columns in the sort order pandas gives ``Path`` objects."""
+    order = sorted(range(len(files)), key=lambda i: files[i])
+    labels = [files[i] for i in order]
+    m = np.asarray(matrix)[np.ix_(order, order)]
+    df = pd.DataFrame(m, index=pd.Index(labels, name="file", dtype=object),
+                      columns=pd.Index(labels, name="file2", dtype=object))
+    df.to_csv(output)
+
+
+def _dist_env():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    return world, rank
+
+
+def lz4_matrix(files, reverse_complement, show_progress):
+    """Phases A-C for ``-c lz4`` on the HIP backend.  Returns the float64 NCD matrix in `files`
+    order on rank 0 (None on other ranks)."""
+    from .hip_backend import HipContext
+
+    world, rank = _dist_env()
+    click.secho("Compressing individual files...", fg="green")
+    it = tqdm(files) if (show_progress and rank == 0) else files
+    seqs = [bytes(extract_sequences(f, reverse_complement=reverse_complement), encoding="utf-8") for f in it]
+    n = len(seqs)
+    ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")))
+    try:
+        ctx.upload(seqs)
+        singles = ctx.singles().astype(np.int64) + GETSIZEOF_OVERHEAD
+        click.secho("Compressing pairs...", fg="green")
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            from .distributed import all_pairs_hip
+            torch.cuda.set_device(ctx.device)
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device))
+            pairs = all_pairs_hip(ctx, n).astype(np.int64) + GETSIZEOF_OVERHEAD
+        else:
+            pairs = ctx.pairs().astype(np.int64) + GETSIZEOF_OVERHEAD
+    finally:
+        ctx.close()
+    if rank != 0:
+        return None
+    return ncd_matrix(singles, pairs)
+
+
+def threadpool_matrix(files, compression, num_threads, save_compression, reverse_complement, show_progress):
+    """The reference's own flow (ref:snacc/cli.py:104-136) for the stdlib codecs."""
+    executor = concurrent.futures.ThreadPoolExecutor(max_workers=num_threads)
+    click.secho("Compressing individual files...", fg="green")
+    compressed_dict = dict(tqdm_parallel_map(
+        executor,
+        lambda x: compressed_size(sequences=x, algorithm=compression, save_directory=save_compression,
+                                  reverse_complement=reverse_complement),
+        show_progress, files))
+    click.secho("Compressing pairs...", fg="green")
+    pair_sizes = dict(tqdm_parallel_map(
+        executor,
+        lambda x: compressed_size(sequences=x, algorithm=compression, save_directory=save_compression,
+                                  reverse_complement=reverse_complement),
+        show_progress, itertools.product(compressed_dict.keys(), repeat=2)))
+    n = len(files)
+    matrix = np.zeros((n, n), dtype=np.float64)
+    for i, a in enumerate(files):
+        for j, b in enumerate(files):
+            matrix[i, j] = compute_distance(compressed_dict[a], compressed_dict[b],
+                                            pair_sizes[(a, b)], pair_sizes[(b, a)])
+    return matrix
+
+
+@click.command(context_settings=dict(help_option_names=["-h", "--help"]))
+@click.argument("sequences", type=click.Path(exists=True, resolve_path=True), nargs=-1)
+@click.option("-f", "--fasta", type=click.Path(dir_okay=False, exists=True, resolve_path=True),
+              multiple=True, hidden=True, help="FASTA file containing sequence to compare.")
+@click.option("-d", "--directory", "directories",
+              type=click.Path(dir_okay=True, file_okay=False, exists=True, resolve_path=True),
+              multiple=True, hidden=True, help="Directory containing FASTA files to compare.")
+@click.option("-n", "--num-threads", "numThreads", type=int, default=None,
+              help="Number of Threads to use (default 5 * number of cores).")
+@click.option("-o", "--output", type=click.Path(dir_okay=False, exists=False),
+              help="The location for the output CSV file.", prompt="Output CSV path")
+@click.option("-s", "--save-compression", "saveCompression",
+              type=click.Path(dir_okay=True, file_okay=False, resolve_path=True), default=None,
+              help="Save compressed sequence files to the specified directory.")
+@click.option("-c", "--compression", default="lzma",
+              type=click.Choice(["lzma", "gzip", "bzip2", "zlib", "lz4"]),
+              help="The compression algorithm to use. Defaults to lzma.")
+@click.option("--show-progress/--no-show-progress", "showProgress", default=True,
+              help="Whether to show a progress bar for computing compression distances.")
+@click.option("-r", "--reverse_complement", is_flag=True, default=False,
+              help="Whether to use the reverse complement of the sequence.")
+@click.option("--log/--no-log", "log", default=True, help="Whether to save a log.")
+def cli(sequences, fasta, directories, numThreads, compression, showProgress, saveCompression, output,
+        reverse_complement, log):
+    start_time = datetime.now()
+
+    if fasta or directories:
+        click.secho("Warning: the -f and -d flags are deprecated and will be removed before release. "
+                    "Please pass files and paths directly without the flags.", fg="yellow")
+    if saveCompression:
+        saveCompression = Path(saveCompression)
+    output = Path(output)
+
+    files = discover_files(sequences, fasta, directories)
+
+    if compression == "lz4":
+        if saveCompression:
+            raise click.UsageError("-s/--save-compression is not available with -c lz4 on the HIP backend "
+                                   "(sizes only; SURVEY.md 8f N4)")
+        matrix = lz4_matrix(files, reverse_complement, showProgress)
+    else:
+        matrix = threadpool_matrix(files, compression, numThreads, saveCompression, reverse_complement,
+                                   showProgress)
+    if matrix is None:          # non-zero rank of a multi-GPU run
+        return
+
+    write_matrix_csv(files, matrix, output)
+
+    if log:
+        rendered = log_template.format(time=datetime.now(),
+                                       method=compression,
+                                       py_version=str(sys.version.replace("\n", "")),
+                                       snacc_version=__version__,
+                                       lz4framed_version=LZ4_BACKEND_VERSION,
+                                       rev_comp=reverse_complement,
+                                       duration=datetime.now() - start_time,
+                                       output_path=output.absolute())
+        with open(output.stem + ".md", "w") as f:
+            print(rendered, file=f)
+            for _f in [str(_file.absolute()) for _file in files]:
+                print("*", _f, file=f)
+
+
+def tqdm_parallel_map(executor, fn, showProgress, *iterables, **kwargs):
+    """``executor.map`` with a tqdm progress bar, results in completion order
+    (ref:snacc/cli.py:162-177)."""
+    futures_list = []
+    for iterable in iterables:
+        futures_list += [executor.submit(fn, i) for i in iterable]
+    done = concurrent.futures.as_completed(futures_list)
+    if showProgress:
+        done = tqdm(done, total=len(futures_list), **kwargs)
+    for f in done:
+        yield f.result()
+
+
+log_template = '''# `snacc` Analysis
+## Run Information
+* Analysis time: {time}
+* Analysis duration: {duration}
+* Compression method: {method}
+* Reverse complement: {rev_comp}
+* Output filepath: {output_path}
+
+## Version Information
+* Python: {py_version}
+* snacc: {snacc_version}
+* py-lz4framed: {lz4framed_version}
+
+## Analyzed Files
+'''
+
+
+if __name__ == "__main__":
+    cli()

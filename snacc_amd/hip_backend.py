@@ -54,6 +54,14 @@ def load():
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "The lz4 path has no CPU fallback.")
     try:
+        # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  A process must end
+        # up with ONE HIP runtime: if torch is installed, load it first so that this library's
+        # NEEDED libamdhip64.so.7 resolves to the copy torch uses (the other order leaves two
+        # runtimes and hipGetDeviceCount() then reports no device).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # missing ROCm runtime etc.
         raise HipBackendError(f"cannot load {LIB_PATH}: {e}") from e

@@ -1,0 +1,27 @@
+"""NCD matrix assembly on the host (float64), ref:snacc/cli.py:131-136 + pairwise_ncd.py:93-111.
+
+Floats are never computed on the GPU: the kernels return integer frame sizes and the
+formula below reproduces the reference's Python arithmetic bit for bit (int -> float64
+true division is correctly rounded in both, and division by a positive number is
+monotonic, so min-then-divide equals divide-then-min)."""
+import sys
+
+import numpy as np
+
+#: ``sys.getsizeof(b"")`` -- the constant the reference adds to every size by measuring the
+#: bytes *object* (ref:snacc/pairwise_ncd.py:90).  33 on 64-bit CPython.
+GETSIZEOF_OVERHEAD = sys.getsizeof(b"")
+
+
+def ncd_matrix(singles, pairs):
+    """singles: (N,) compressed sizes C(x_i); pairs: (N, N) with pairs[i, j] = C(x_i + x_j).
+    Sizes must already include the getsizeof overhead.  Returns the (N, N) float64 matrix
+    D[i, j] = compute_distance(C_i, C_j, C_ij, C_ji)."""
+    s = np.asarray(singles, dtype=np.int64)
+    p = np.asarray(pairs, dtype=np.int64)
+    x = s[:, None]
+    y = s[None, :]
+    lo = np.minimum(x, y)
+    hi = np.maximum(x, y)
+    num = np.minimum(p, p.T) - lo
+    return num.astype(np.float64) / hi.astype(np.float64)

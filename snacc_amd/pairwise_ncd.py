@@ -1,0 +1,128 @@
+"""Drop-in for ``snacc.pairwise_ncd`` (ref:snacc/pairwise_ncd.py) with the lz4 codec on MI355X.
+
+Same three functions, same signatures and error behaviour:
+
+* :func:`extract_sequences`  -- ref:snacc/pairwise_ncd.py:15-39
+* :func:`compressed_size`    -- ref:snacc/pairwise_ncd.py:42-90
+* :func:`compute_distance`   -- ref:snacc/pairwise_ncd.py:93-111
+
+``algorithm == "lz4"`` goes to the HIP backend (``libsnacc_hip.so``) -- there is no CPU
+fallback for it.  The other codecs are the stdlib calls the reference makes (out of scope
+for the GPU).  :func:`all_pairs_lz4` is the batched entry the CLI uses
+instead of N*N single calls.
+"""
+import bz2
+import gzip
+import lzma
+import os
+import sys
+import zlib
+from pathlib import Path
+
+import numpy as np
+
+from . import fasta
+from .matrix import GETSIZEOF_OVERHEAD, ncd_matrix
+
+_EXTENSION = {"lzma": ".lzma", "gzip": ".gz", "bzip2": ".bz2", "zlib": ".ZLIB", "lz4": ".lz4"}
+
+_ctx = None
+
+
+def _hip_context():
+    """Process-wide device context for single-item calls (device = LOCAL_RANK or 0)."""
+    global _ctx
+    if _ctx is None:
+        from .hip_backend import HipContext
+        _ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")))
+    return _ctx
+
+
+def extract_sequences(sequences, reverse_complement=False):
+    """Concatenated sequences of a FASTA file, or of two files for a tuple."""
+    if type(sequences) == tuple:
+        return (extract_sequences(sequences[0], reverse_complement=reverse_complement)
+                + extract_sequences(sequences[1], reverse_complement=reverse_complement))
+    seq = fasta.read_sequence(sequences.absolute(), reverse_complement)
+    if not seq:
+        raise ValueError(f"No sequence extracted. Ensure that file {sequences.absolute()} contains a proper "
+                         "FASTA definition line (i.e. a line that starts with '>sequence_name').")
+    return seq
+
+
+def compressed_size(sequences, algorithm, reverse_complement=False, save_directory=None, BWT=False, bwte_inputs={}):
+    """``(sequences, size)`` where size is what the reference reports: ``sys.getsizeof`` of the
+    compressed bytes object (payload length + 33).  ``BWT``/``bwte_inputs`` are accepted and
+    ignored, as in the reference."""
+    if type(sequences) == tuple:
+        parts = [extract_sequences(s, reverse_complement=reverse_complement) for s in sequences]
+    else:
+        parts = [extract_sequences(sequences, reverse_complement=reverse_complement)]
+    file_ext = _EXTENSION[algorithm]          # KeyError for unknown algorithms, as in the reference
+
+    if algorithm == "lz4":
+        if save_directory:
+            raise NotImplementedError("lz4 on the HIP backend returns sizes only; saving the compressed "
+                                      "blob (-s with -c lz4) is not implemented (SURVEY.md 8f N4)")
+        ctx = _hip_context()
+        ctx.upload([bytes(p, encoding="utf-8") for p in parts])
+        if len(parts) == 2:
+            n = int(ctx.pairs_list([(0, 1)])[0])
+        else:
+            n = int(ctx.singles()[0])
+        return (sequences, n + GETSIZEOF_OVERHEAD)
+
+    sequence = bytes("".join(parts), encoding="utf-8")
+    if algorithm == "lzma":
+        compressed_seq = lzma.compress(sequence)
+    elif algorithm == "gzip":
+        compressed_seq = gzip.compress(sequence)
+    elif algorithm == "bzip2":
+        compressed_seq = bz2.compress(sequence)
+    elif algorithm == "zlib":
+        compressed_seq = zlib.compress(sequence)
+    if save_directory:
+        if type(sequences) == tuple:
+            out_file = sequences[0].stem + sequences[1].name
+        else:
+            out_file = sequences.name
+        with open(os.path.join(save_directory.absolute(), out_file + file_ext), "wb") as f:
+            f.write(compressed_seq)
+    return (sequences, sys.getsizeof(compressed_seq))
+
+
+def compute_distance(x, y, cxy, cyx):
+    """Normalized compression distance from four compressed sizes."""
+    if x > y:
+        return min((cxy - y) / x, (cyx - y) / x)
+    elif y > x:
+        return min((cxy - x) / y, (cyx - x) / y)
+    else:
+        return min((cxy - x) / x, (cyx - x) / x)
+
+
+def all_pairs_lz4(sequences, ctx=None, rows=None):
+    """Batched phase A + B of ref:snacc/cli.py:108-129 for the lz4 codec.
+
+    sequences: list of ``bytes``/``str`` (already extracted).  Returns ``(singles, pairs)`` as
+    int64 arrays *including* the getsizeof overhead; ``rows=(r0, r1)`` restricts phase B to a
+    row range (multi-GPU sharding)."""
+    own = ctx is None
+    if own:
+        from .hip_backend import HipContext
+        ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")))
+    try:
+        ctx.upload(sequences)
+        singles = ctx.singles().astype(np.int64) + GETSIZEOF_OVERHEAD
+        r0, r1 = rows if rows is not None else (0, len(sequences))
+        pairs = ctx.pairs(r0, r1).astype(np.int64) + GETSIZEOF_OVERHEAD
+    finally:
+        if own:
+            ctx.close()
+    return singles, pairs
+
+
+def ncd_matrix_lz4(sequences, ctx=None):
+    """Full N x N NCD matrix (float64) for extracted sequences, lz4 codec, one GPU."""
+    singles, pairs = all_pairs_lz4(sequences, ctx=ctx)
+    return ncd_matrix(singles, pairs)

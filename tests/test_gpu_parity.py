@@ -1,0 +1,187 @@
+"""GPU parity tests: the HIP path, through the C-ABI, against the oracle on the same seeded
+inputs, against the committed golden vectors, and -- at BASELINE.json's full 1 Mbp size --
+through size-independent properties.  Bit-exact everywhere (integer sizes); NCD floats are
+derived on the host from equal integers and compared exactly (tolerance of north_star: 1e-6)."""
+import numpy as np
+import pytest
+
+from conftest import lcg_bytes, materialise_cli_set
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from snacc_amd import hip_backend
+    hip_backend.load()                       # raises if libsnacc_hip.so is missing: no silent fallback
+    return hip_backend
+
+
+def _check_all(hip, oracle, seqs, **opts):
+    with hip.HipContext(0, **opts) as ctx:
+        ctx.upload(seqs)
+        s = ctx.singles()
+        p = ctx.pairs()
+        packed = ctx.num_packed
+    exp_s = np.array([oracle.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = np.array([[oracle.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    assert np.array_equal(s, exp_s)
+    assert np.array_equal(p, exp_p)
+    return packed
+
+
+def test_tiny_and_empty_inputs(hip, oracle_mod):
+    seqs = [b"ACGT" * 10, b"ACGTTGCA" * 3, b"A", b"", b"ACGTN" * 5, b"GATTACA" * 1000, b"ACGTACGTACGTA", b"ACGTACGTACGT"]
+    _check_all(hip, oracle_mod, seqs)
+
+
+def test_lcg_100k_fast_and_generic_paths(hip, oracle_mod):
+    seqs = [oracle_mod.lcg_genome(1 + i, 100000) for i in range(6)]
+    assert _check_all(hip, oracle_mod, seqs) == 6
+    _check_all(hip, oracle_mod, seqs, force_generic=1)
+
+
+def test_ragged_lengths_around_block_edges(hip, oracle_mod):
+    lens = [65536, 65537, 131072, 200001, 30000, 35536, 12, 65535 + 65536, 65548, 4, 196608]
+    seqs = [oracle_mod.lcg_genome(11 + i, n) for i, n in enumerate(lens)]
+    _check_all(hip, oracle_mod, seqs)
+
+
+def test_mixed_alphabets_raw_blocks_and_n_runs(hip, oracle_mod):
+    rng = np.random.default_rng(7)
+    o = oracle_mod
+    nrun = np.concatenate([o.lcg_genome(22, 70000), np.frombuffer(b"N" * 500, dtype=np.uint8), o.lcg_genome(23, 70000)])
+    seqs = [o.lcg_genome(21, 150000), rng.integers(0, 256, 140000, dtype=np.uint8), nrun,
+            np.tile(o.lcg_genome(24, 700), 300),
+            np.frombuffer(lcg_bytes(31, 90000, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8),
+            np.frombuffer(bytes(o.lcg_genome(25, 120000)).lower(), dtype=np.uint8)]
+    assert _check_all(hip, oracle_mod, seqs) == 2
+
+
+def test_long_matches_and_low_complexity(hip, oracle_mod):
+    o = oracle_mod
+    rep = np.tile(o.lcg_genome(32, 5000), 40)
+    seqs = [np.tile(o.lcg_genome(31, 37), 5000), rep, o.lcg_mutant(rep, 5),
+            np.frombuffer(b"A" * 300000, dtype=np.uint8), o.lcg_genome(33, 250000),
+            np.frombuffer(b"AC" * 100000, dtype=np.uint8)]
+    assert _check_all(hip, oracle_mod, seqs) == 6
+
+
+def test_related_genomes_same_ancestor(hip, oracle_mod):
+    o = oracle_mod
+    anc = o.lcg_genome(40, 180000)
+    seqs = [anc] + [o.lcg_mutant(anc, 50 + i) for i in range(4)] + [anc[::-1].copy()]
+    _check_all(hip, oracle_mod, seqs)
+
+
+def test_golden_frame_sizes_through_cabi(hip, golden, oracle_mod):
+    """The liblz4 1.9.3 sizes recorded in golden.json, computed by the GPU."""
+    o = oracle_mod
+    g = golden["liblz4_frame_sizes"]
+    row = g["lcg_seed1_2_mut3"][1]                     # n = 100 000
+    x, y = o.lcg_genome(1, row["n"]), o.lcg_genome(2, row["n"])
+    z = o.lcg_mutant(x, 3)
+    with hip.HipContext(0) as ctx:
+        ctx.upload([x, y, z])
+        assert ctx.singles().tolist() == [row["x"], row["y"], row["z"]]
+        got = ctx.pairs_list([(0, 1), (1, 0), (0, 0), (0, 2), (2, 0)]).tolist()
+        assert got == [row["xy"], row["yx"], row["xx"], row["xz"], row["zx"]]
+        rag = g["lcg_ragged"]
+        ctx.upload([o.lcg_genome(r["seed"], r["n"]) for r in rag])
+        assert ctx.singles().tolist() == [r["size"] for r in rag]
+        oth = g["other_alphabets"]
+        ctx.upload([lcg_bytes(r["seed"], r["n"], bytes.fromhex(r["alphabet_hex"])) for r in oth])
+        assert ctx.singles().tolist() == [r["size"] for r in oth]
+
+
+def test_content_size_option_adds_eight_bytes(hip, oracle_mod):
+    seqs = [oracle_mod.lcg_genome(3, 70000), b"ACGT" * 10]
+    with hip.HipContext(0) as a, hip.HipContext(0, content_size=1) as b:
+        a.upload(seqs)
+        b.upload(seqs)
+        assert np.array_equal(a.singles() + 8, b.singles())
+        assert np.array_equal(a.pairs() + 8, b.pairs())
+
+
+def test_row_tiles_and_pair_lists_agree_with_full_matrix(hip, oracle_mod):
+    seqs = [oracle_mod.lcg_genome(60 + i, 70000 + 1111 * i) for i in range(9)]
+    with hip.HipContext(0, fast_lanes=3, fast_waves=2) as ctx:
+        ctx.upload(seqs)
+        full = ctx.pairs()
+        tiles = np.concatenate([ctx.pairs(0, 2), ctx.pairs(2, 7), ctx.pairs(7, 9)])
+        assert np.array_equal(full, tiles)
+        ij = [(i, j) for i in range(9) for j in range(9)][::-1]
+        assert np.array_equal(ctx.pairs_list(ij), full[::-1, ::-1].reshape(-1))
+    exp = np.array([[oracle_mod.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    assert np.array_equal(full, exp)
+
+
+def test_python_api_single_items(hip, golden):
+    """compressed_size(path | (path, path), "lz4") -- the reference's granularity."""
+    from pathlib import Path
+    from snacc_amd import compressed_size
+    p = Path(__file__).parent / "golden" / "sample_crlf.fa"
+    with open(p, "w", newline="") as f:
+        f.write(">derice\r\nACTGACTAGCTAGCTAACTG\r\n>sanka\r\nGCATCGTAGCTAGCTACGAT\r\n"
+                ">junior\r\nCATCGATCGTACGTACGTAG\r\n>yul\r\nATCGATCGATCGTACGATCG")
+    try:
+        g = golden["sample_fa"]
+        assert compressed_size(p, "lz4") == (p, g["sizes_single"]["lz4"])
+        assert compressed_size((p, p), "lz4") == ((p, p), g["sizes_selfpair"]["lz4"])
+        assert compressed_size(p, "lz4", reverse_complement=True)[1] == g["sizes_single_rc_lz4"]
+    finally:
+        p.unlink()
+
+
+@pytest.mark.parametrize("set_name", ["acgt_small", "ragged_blocks"])
+@pytest.mark.parametrize("rc", [False, True])
+def test_cli_lz4_csv_equals_reference_cli(hip, golden, oracle_mod, tmp_path, monkeypatch, set_name, rc):
+    """`snacc <dir> -c lz4 [-r]` end to end on the GPU == the CSV the reference CLI wrote."""
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    spec = golden["cli_lz4"]["sets"][set_name]
+    d = materialise_cli_set(oracle_mod, spec, tmp_path / "fa")
+    out = tmp_path / "out.csv"
+    monkeypatch.chdir(tmp_path)
+    args = [str(d), "-o", str(out), "-c", "lz4", "-n", "1", "--no-show-progress"] + (["-r"] if rc else [])
+    res = CliRunner().invoke(cli, args)
+    assert res.exit_code == 0, res.output
+    want = golden["cli_lz4"]["outputs"][set_name]["csv_rc" if rc else "csv"].replace("{DIR}", str(d))
+    assert out.read_text() == want
+    log = (tmp_path / "out.md").read_text()
+    assert "* Compression method: lz4" in log and f"* Reverse complement: {rc}" in log
+
+
+def test_full_size_1mbp_properties(hip, golden, oracle_mod):
+    """BASELINE.json size (1 Mbp genomes): oracle on a sample of pairs, plus size-independent
+    properties over ALL pairs: the 2-bit kernel and the byte kernel (independent code) agree,
+    results do not depend on the launch shape, and the NCD matrix is exactly symmetric."""
+    o = oracle_mod
+    n, L = 12, 1_000_000
+    seqs = [o.lcg_genome(1 + i, L) for i in range(n)]
+    seqs[5] = o.lcg_mutant(seqs[0], 3)
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        s = ctx.singles()
+        p = ctx.pairs()
+    with hip.HipContext(0, fast_lanes=10, fast_waves=8) as ctx:
+        ctx.upload(seqs)
+        assert np.array_equal(ctx.pairs(), p)
+    with hip.HipContext(0, force_generic=1) as ctx:
+        ctx.upload(seqs)
+        assert np.array_equal(ctx.singles(), s)
+        assert np.array_equal(ctx.pairs(0, 3), p[:3])           # byte kernel == 2-bit kernel
+    row = golden["liblz4_frame_sizes"]["lcg_seed1_2_mut3"][2]
+    assert (int(s[0]), int(s[1]), int(s[5])) == (row["x"], row["y"], row["z"])
+    assert (int(p[0, 1]), int(p[1, 0]), int(p[0, 0]), int(p[0, 5]), int(p[5, 0])) == \
+           (row["xy"], row["yx"], row["xx"], row["xz"], row["zx"])
+    for i, j in [(2, 3), (7, 2), (11, 11), (4, 9), (9, 4), (6, 0)]:
+        assert int(p[i, j]) == o.lz4f_size_pair(seqs[i], seqs[j])
+    from snacc_amd.matrix import ncd_matrix
+    from snacc_amd.pairwise_ncd import compute_distance
+    m = ncd_matrix(s.astype(np.int64) + 33, p.astype(np.int64) + 33)
+    assert np.array_equal(m, m.T)
+    assert m[0, 1] == 0.999350356687629 and m[0, 0] == 1.000420899139182
+    assert abs(m[3, 8] - compute_distance(int(s[3]) + 33, int(s[8]) + 33, int(p[3, 8]) + 33, int(p[8, 3]) + 33)) <= 1e-6

@@ -1,0 +1,131 @@
+"""Host side of the drop-in (no GPU): FASTA ingest, reverse complement, the NCD formula, the
+matrix assembly and the CSV writer -- against the outputs of the reference's own Python
+recorded in tests/golden/golden.json."""
+import itertools
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import materialise_cli_set
+from snacc_amd import compressed_size, compute_distance
+from snacc_amd import fasta
+from snacc_amd.cli import discover_files, write_matrix_csv
+from snacc_amd.matrix import GETSIZEOF_OVERHEAD, ncd_matrix
+from snacc_amd.pairwise_ncd import extract_sequences
+
+SAMPLE_TEXT = (">derice\r\nACTGACTAGCTAGCTAACTG\r\n>sanka\r\nGCATCGTAGCTAGCTACGAT\r\n"
+               ">junior\r\nCATCGATCGTACGTACGTAG\r\n>yul\r\nATCGATCGATCGTACGATCG")   # ref:test_dataset/sample.fa
+
+
+@pytest.fixture()
+def sample_fa(tmp_path):
+    p = tmp_path / "sample.fa"
+    with open(p, "w", newline="") as f:
+        f.write(SAMPLE_TEXT)
+    return p
+
+
+def test_extract_sequences_sample(golden, sample_fa):
+    g = golden["sample_fa"]
+    assert extract_sequences(sample_fa) == g["extract"]
+    assert extract_sequences(sample_fa, reverse_complement=True) == g["extract_rc"]
+    assert extract_sequences((sample_fa, sample_fa)) == g["extract_pair"]
+
+
+def test_getsizeof_overhead():
+    assert GETSIZEOF_OVERHEAD == 33
+
+
+def test_stdlib_codecs_match_reference(golden, sample_fa):
+    g = golden["sample_fa"]
+    for algo in ("gzip", "zlib", "bzip2", "lzma"):
+        key, size = compressed_size(sample_fa, algo)
+        assert key == sample_fa and size == g["sizes_single"][algo]
+        key, size = compressed_size((sample_fa, sample_fa), algo)
+        assert key == (sample_fa, sample_fa) and size == g["sizes_selfpair"][algo]
+
+
+def test_unknown_algorithm_is_keyerror(sample_fa):
+    with pytest.raises(KeyError):
+        compressed_size(sample_fa, "snappy")
+
+
+def test_empty_fasta_raises_valueerror(tmp_path):
+    p = tmp_path / "empty.fa"
+    p.write_text("no header here\nACGT\n")
+    with pytest.raises(ValueError, match="No sequence extracted"):
+        extract_sequences(p)
+
+
+def test_save_directory_stdlib(tmp_path, sample_fa):
+    out = tmp_path / "blobs"
+    out.mkdir()
+    compressed_size(sample_fa, "gzip", save_directory=out)
+    compressed_size((sample_fa, sample_fa), "zlib", save_directory=out)
+    assert (out / "sample.fa.gz").exists() and (out / "samplesample.fa.ZLIB").exists()
+
+
+def test_fasta_reader_details(tmp_path):
+    p = tmp_path / "x.fna"
+    p.write_text("; comment\n\n>r1 desc\nAC GT\nacgtn \n\n>r2\n>r3\nNNRY\n")
+    recs = list(fasta.read_fasta_records(p))
+    assert recs == [("r1 desc", "ACGTacgtn"), ("r2", ""), ("r3", "NNRY")]
+    assert fasta.read_sequence(p) == "ACGTacgtnNNRY"
+    # per-record reverse complement, records kept in order (ref:snacc/pairwise_ncd.py:32-36)
+    assert fasta.read_sequence(p, True) == "nacgtACGT" + "" + "RYNN"
+
+
+def test_reverse_complement_tables():
+    assert fasta.reverse_complement("ACGTMRWSYKVHDBXN") == "NXVHDBMRSWYKACGT"
+    assert fasta.reverse_complement("acgu") == "acgu"
+    assert fasta.reverse_complement("AC-GT*") == "*AC-GT"
+    with pytest.raises(ValueError):
+        fasta.reverse_complement("ACGTU")
+
+
+def test_compute_distance_kats(golden):
+    for kat in golden["compute_distance"]:
+        assert compute_distance(*kat["args"]) == kat["result"], kat["args"]
+    assert compute_distance(1174721, 1173133, 1242873, 1242873) == 0.05936728806244206
+
+
+def test_ncd_matrix_equals_scalar_formula():
+    rng = np.random.default_rng(3)
+    n = 17
+    s = rng.integers(500, 600000, n)
+    s[3] = s[5]                                   # exercise the x == y branch off the diagonal
+    p = rng.integers(600000, 1300000, (n, n))
+    m = ncd_matrix(s, p)
+    for i, j in itertools.product(range(n), repeat=2):
+        assert m[i, j] == compute_distance(int(s[i]), int(s[j]), int(p[i, j]), int(p[j, i]))
+    assert np.array_equal(m, m.T)
+
+
+@pytest.mark.parametrize("set_name", ["acgt_small", "ragged_blocks"])
+@pytest.mark.parametrize("rc", [False, True])
+def test_csv_from_oracle_sizes_matches_reference_cli(golden, oracle_mod, tmp_path, set_name, rc):
+    """discover -> extract (once per file) -> sizes (oracle as the checker) -> NCD -> CSV must equal,
+    byte for byte, what the reference CLI wrote for the same FASTA set."""
+    spec = golden["cli_lz4"]["sets"][set_name]
+    d = materialise_cli_set(oracle_mod, spec, tmp_path / "fa")
+    files = discover_files([str(d)])
+    assert [f.name for f in files] == sorted(spec["files"])
+    seqs = [extract_sequences(f, reverse_complement=rc).encode() for f in files]
+    singles = np.array([oracle_mod.lz4f_size(s) for s in seqs]) + GETSIZEOF_OVERHEAD
+    pairs = np.array([[oracle_mod.lz4f_size_pair(a, b) for b in seqs] for a in seqs]) + GETSIZEOF_OVERHEAD
+    out = tmp_path / "out.csv"
+    write_matrix_csv(files, ncd_matrix(singles, pairs), out)
+    want = golden["cli_lz4"]["outputs"][set_name]["csv_rc" if rc else "csv"].replace("{DIR}", str(d))
+    assert out.read_text() == want
+
+
+def test_discover_files_rules(tmp_path):
+    d = tmp_path / "in"
+    (d / "sub").mkdir(parents=True)
+    for name in ("b.FASTA", "a.fa", "c.txt", "d.faa", "sub/e.fa"):
+        (d / name).write_text(">x\nACGT\n")
+    extra = tmp_path / "z.txt"
+    extra.write_text(">x\nACGT\n")
+    files = discover_files([str(d), str(extra), str(d / "a.fa")])
+    assert [f.name for f in files] == ["a.fa", "b.FASTA", "d.faa", "z.txt"]     # non-recursive, dedup, sorted
