@@ -34,7 +34,7 @@ struct snk_ctx_impl {
     std::vector<uint32_t> len;
     std::vector<uint8_t> is_packed;
     uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_zero = nullptr;
-    const uint8_t **d_bytes_ptr = nullptr, **d_packed_ptr = nullptr;
+    const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
     uint16_t *d_lut_slot = nullptr; uint32_t *d_lut_hash = nullptr;
@@ -70,7 +70,7 @@ template <typename T> void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p =
 
 void free_sequences(snk_ctx_impl *c)
 {
-    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_ptr);
+    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast);
     dfree(c->d_snap_gen); dfree(c->d_single);
     c->n = 0; c->n_packed = 0; c->len.clear(); c->is_packed.clear(); c->singles_done = false;
@@ -105,7 +105,7 @@ bool build_luts(std::vector<uint16_t> &slot, std::vector<uint32_t> &hash)
 SnkTables make_tables(const snk_ctx_impl *c)
 {
     SnkTables T;
-    T.bytes = c->d_bytes_ptr; T.packed = c->d_packed_ptr; T.len = c->d_len;
+    T.bytes = c->d_bytes_ptr; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
     T.lut_slot = c->d_lut_slot; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
@@ -323,7 +323,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
 
     const size_t n = (size_t)n_seq;
     std::vector<size_t> boff(n), poff(n);
-    size_t btot = SNK_PAD, ptot = SNK_PAD;
+    size_t btot = SNK_PAD, ptot = 4 * SNK_PAD;      // the packed arena starts with a zero region (empty suffix)
     for (size_t g = 0; g < n; ++g) {
         if (lens[g] >= 0x7E000000ull) return fail(c, SNK_E_TOOBIG, "sequence %zu too long (%llu B)", g, (unsigned long long)lens[g]);
         if (lens[g] && !seqs[g]) return fail(c, SNK_E_ARG, "sequence %zu is NULL", g);
@@ -362,6 +362,8 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         c->is_packed[g] = (flags[g] & 1u) && lens[g] > 0;
         if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
     }
+    if (ptot >= 0xFFF00000ull)
+        return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the 4 GiB offset range", ptot);
     HIPCHK(c, hipMalloc((void **)&c->d_packed, ptot));
     HIPCHK(c, hipMemsetAsync(c->d_packed, 0, ptot, c->stream));
     for (size_t g = 0; g < n; ++g) {
@@ -374,15 +376,15 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipGetLastError());
 
     // ---- per-sequence tables ------------------------------------------------------------------
-    std::vector<const uint8_t *> bp(n), pp(n);
+    std::vector<const uint8_t *> bp(n); std::vector<uint32_t> pp(n);
     std::vector<uint32_t> spos(n);
     for (size_t g = 0; g < n; ++g) {
         bp[g] = c->d_bytes + boff[g];
-        pp[g] = c->is_packed[g] ? c->d_packed + poff[g] : nullptr;
+        pp[g] = c->is_packed[g] ? (uint32_t)poff[g] : 0u;
         spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
     }
     HIPCHK(c, hipMalloc((void **)&c->d_bytes_ptr, n * sizeof(void *)));
-    HIPCHK(c, hipMalloc((void **)&c->d_packed_ptr, n * sizeof(void *)));
+    HIPCHK(c, hipMalloc((void **)&c->d_packed_off, n * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&c->d_len, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_pos, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_out, n * 4));
@@ -390,7 +392,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipMalloc((void **)&c->d_snap_fast, n * SNK_FSLOTS * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_gen, n * 4096 * 4));
     HIPCHK(c, hipMemcpy(c->d_bytes_ptr, bp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_packed_ptr, pp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_packed_off, pp.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_len, c->len.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_snap_pos, spos.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->d_snap_out, 0, n * 4, c->stream));

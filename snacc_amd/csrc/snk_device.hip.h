@@ -44,7 +44,8 @@ struct SnkJob {
 struct SnkTables {
     // per-sequence, all device pointers
     const uint8_t  *const *bytes;     // ASCII, padded
-    const uint8_t  *const *packed;    // 2-bit, padded (NULL entries for non-ACGT sequences)
+    const uint8_t  *packed_arena;     // 2-bit packed sequences, one allocation < 4 GiB; starts with 4*SNK_PAD zero bytes
+    const uint32_t *packed_off;       // byte offset of each packed sequence in the arena (0 = not packed)
     const uint32_t *len;
     const uint32_t *snap_pos;         // block-aligned prefix length covered by the snapshot (0 = none)
     uint32_t       *snap_out;         // frame bytes (header included) after snap_pos
@@ -102,31 +103,31 @@ __device__ __forceinline__ uint32_t snk_ld4g(snk_g8 *p)
 }
 
 struct SnkFastSrc {
-    snk_g8 *xp, *yp;          // packed; base i of a sequence at bits 2(i&3) of byte i>>2
+    snk_g8 *arena;            // wave-uniform base of the packed arena (SGPR base + 32-bit lane offsets)
+    uint32_t xoff, yoff;      // byte offsets of the two packed sequences inside the arena
     uint32_t lx;
 };
 
-// 32-bit window over the virtual concatenation x+y: the 16 bases [p-4, p+12),
-// base p-4 at bits 0..1.  5-mer at p = bits 8..17, 5-mer at p-2 = bits 4..13.
-__device__ __forceinline__ uint32_t snk_w32_at(snk_g8 *b, int32_t q)
+// 32-bit window: the 16 bases [q, q+16) of the sequence at arena offset `off`, base q at bits 0..1.
+__device__ __forceinline__ uint32_t snk_w32_at(snk_g8 *arena, uint32_t off, int32_t q)
 {
-    const uint64_t v = snk_ld8g(b + (q >> 2));
+    const uint64_t v = snk_ld8g(arena + (size_t)(uint32_t)((int32_t)off + (q >> 2)));
     return __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, (uint32_t)(q & 3) * 2u);
 }
 
+// Window over the virtual concatenation x+y at stream position p: bases [p-4, p+12).
+// 5-mer at p = bits 8..17, 5-mer at p-2 = bits 4..13.
 __device__ __forceinline__ uint32_t snk_fetch32(const SnkFastSrc &s, uint32_t p)
 {
     const int32_t q0 = (int32_t)p - 4;
     const bool inx = (p + 12u <= s.lx);
     const bool iny = (q0 >= (int32_t)s.lx);
-    if (__builtin_expect(inx | iny, 1)) {
-        const int32_t q = iny ? q0 - (int32_t)s.lx : q0;
-        return snk_w32_at(iny ? s.yp : s.xp, q);
-    }
+    if (__builtin_expect(inx | iny, 1))
+        return snk_w32_at(s.arena, iny ? s.yoff : s.xoff, iny ? q0 - (int32_t)s.lx : q0);
     // seam: q0 < lx < q0 + 16.  x is zero padded beyond lx.
-    const uint32_t xv = snk_w32_at(s.xp, q0);
+    const uint32_t xv = snk_w32_at(s.arena, s.xoff, q0);
     const uint32_t sh = 2u * (uint32_t)((int32_t)s.lx - q0);        // 2..30
-    return xv | ((uint32_t)snk_ld8g(s.yp) << sh);
+    return xv | ((uint32_t)snk_ld8g(s.arena + (size_t)s.yoff) << sh);
 }
 
 __device__ __forceinline__ uint32_t snk_base_at(const SnkFastSrc &s, uint32_t p)
@@ -134,128 +135,234 @@ __device__ __forceinline__ uint32_t snk_base_at(const SnkFastSrc &s, uint32_t p)
     return snk_fetch32(s, p + 4u) & 3u;
 }
 
-// Cursor-side reservoir: 32 packed bases [rb, rb+32) of ONE source sequence in
-// registers (r0, r1) plus the next 16 (nx) already in flight, so the window at the
-// probe position costs no memory latency.  (rb - org) % 4 == 0.
+// Cursor-side reservoir: 32 packed bases [rb, rb+32) of ONE source sequence in registers
+// (r0, r1) plus the next 16 (nx) already in flight, so the window at the probe position costs
+// no memory latency.  (rb - org) % 4 == 0.  lim = 0 marks "no usable window".
 struct SnkWin {
-    snk_g8 *src;
-    uint32_t org;      // stream position of base 0 of src (0 for x, lx for y)
+    uint32_t soff;     // arena offset of the source sequence
+    uint32_t org;      // stream position of base 0 of the source (0 for x, lx for y)
     uint32_t rb;       // stream position of bit 0 of r0
     uint32_t lim;      // largest probe position this source can serve
     uint32_t r0, r1, nx;
 };
 
-__device__ __forceinline__ void snk_win_init(SnkWin &w, snk_g8 *src, uint32_t org, uint32_t lim, uint32_t cur)
+__device__ __forceinline__ void snk_win_init(SnkWin &w, snk_g8 *arena, uint32_t soff, uint32_t org,
+                                             uint32_t lim, uint32_t cur)
 {
-    w.src = src; w.org = org; w.lim = lim;
+    w.soff = soff; w.org = org; w.lim = lim;
     w.rb = org + ((cur - 4u - org) & ~3u);
-    snk_g8 *p = src + ((w.rb - org) >> 2);
+    snk_g8 *p = arena + (size_t)(soff + ((w.rb - org) >> 2));
     w.r0 = snk_ld4g(p); w.r1 = snk_ld4g(p + 4); w.nx = snk_ld4g(p + 8);
 }
 
-struct SnkFastState {
+// Everything one lane (= one chain = one ordered pair) carries through the flat parse loop.
+struct SnkFastLane {
+    SnkFastSrc s;
+    uint32_t n, spos;
+    int32_t xi, snap;
+    uint32_t out_idx;
+    // progress over the frame
+    uint32_t pos, total, iend, blen, blocks_left;
+    bool first, in_block;
+    // parse state inside the current block
     uint32_t cur, step, nb, anchor, op;
     uint32_t mfl1, mlimit, olimit, base;   // base = stream position of the block start
-    bool pending;
+    uint32_t endcode;                      // 0 running, 1 ends with last-literals, 2 liblz4 gave up (raw)
+    bool pending;                          // put(cur-2) owed before the next probe
+    bool yflag;                            // whole block lies > 64 KiB + 8 past the seam, window on y
+    SnkWin w;
 };
 
-// One probe of the flat parse loop.  Returns 0 = continue, 1 = block ends with
-// last-literals, 2 = liblz4 gives up on the block (stored raw).
-// YONLY: wave-uniform promise that every lane's cursor is > 64 KiB + 4 past the
-// seam, so cursor and candidate windows both come from y.
-template <bool YONLY>
-__device__ __forceinline__ int snk_fast_probe(SnkFastState &st, SnkWin &w, const SnkFastSrc &s,
-                                              uint16_t *tbl, uint32_t *bm, const uint16_t *slot)
+// Rare path (once per 64 KiB): close the finished block, age the table, open the next block.
+// Returns true when the frame is complete (size written).
+__device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                                 const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
-    const uint32_t cur = st.cur;
-    const uint32_t next = cur + st.step;
-    if (__builtin_expect(next > st.mfl1, 0)) return 1;
-
-    // ---- cursor window from registers ----
-    uint32_t wc;
-    {
-        uint32_t o = cur - 4u - w.rb;                        // need 0 <= o <= 15
-        if ((o - 16u) < 16u) {                               // slide by 16 bases (every ~3 probes)
-            w.r0 = w.r1; w.r1 = w.nx; w.rb += 16u; o -= 16u;
-            w.nx = snk_ld4g(w.src + ((w.rb + 32u - w.org) >> 2));
+    if (L.in_block) {
+        uint32_t payload = L.blen;
+        if (L.endcode != 2u) {
+            const uint32_t run = L.iend - L.anchor;
+            if (L.op + run + 1u + (run + 240u) / 255u <= L.olimit)
+                payload = L.op + 1u + snk_lit_ext(run) + run;
         }
-        if (__builtin_expect(o > 15u || cur > w.lim, 0)) {   // long jump / source change / seam
-            if (cur >= s.lx + 4u)                        snk_win_init(w, s.yp, s.lx, 0xFFFFFFFFu, cur);
-            else if (cur >= 4u && cur + 12u <= s.lx)     snk_win_init(w, s.xp, 0u, s.lx - 12u, cur);
-            else                                         w.rb = 0x80000000u;     // slow path
-            o = cur - 4u - w.rb;
+        L.total += 4u + payload;
+        L.pos = L.iend;
+        L.in_block = false;
+        L.endcode = 0u;
+    }
+    for (;;) {
+        if (L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
+            // prefix snapshot: absolute positions; entries older than one block -> 0 (too far for good)
+            uint32_t *dst = T.snap_fast + (size_t)L.xi * SNK_FSLOTS;
+            for (uint32_t t = 0; t < SNK_FSLOTS; ++t)
+                dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.pos - 65536u + tbl[t]) : 0u;
+            T.snap_out[L.xi] = L.total;
         }
-        if (YONLY || __builtin_expect(o <= 15u, 1)) wc = __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
-        else                                        wc = snk_fetch32(s, cur);
-    }
-    // ---- table probe: two LDS round trips (slot LUT, then table + bitmap) ----
-    const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
-    const uint32_t s2 = slot[(wc >> 4) & 1023u];             // slot of the 5-mer at cur-2
-    const uint32_t e = tbl[s1];
-    const uint32_t bw = bm[s1 >> 5];
-    const uint32_t c = cur - st.base;                        // offset in the block, 1..65535
-    const uint32_t bit1 = 1u << (s1 & 31u);
-    const bool iscur = (bw & bit1) != 0u;
-    uint32_t cand = st.base + e - (iscur ? 0u : 65536u);
-    bool valid = iscur | (e > c);
-    if (st.pending) {
-        // liblz4 puts cur-2 BEFORE it reads the slot of cur: same slot => candidate is cur-2
-        if (s2 == s1) { cand = cur - 2u; valid = true; }
-        tbl[s2] = (uint16_t)(c - 2u);
-        atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
-    }
-    tbl[s1] = (uint16_t)c;
-    if (!iscur) atomicOr(&bm[s1 >> 5], bit1);
-    { const uint32_t s3 = st.nb >> 6; st.step = s3 ? s3 : 1u; st.nb++; }
-    cand = valid ? cand : cur;                               // keep the fetch in bounds
-
-    // ---- candidate window: the one global-memory round trip of the probe ----
-    const uint32_t wd = YONLY ? snk_w32_at(s.yp, (int32_t)(cand - 4u - s.lx)) : snk_fetch32(s, cand);
-    const uint32_t x = wc ^ wd;
-    uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;   // equal bases from cur, 0..12
-    if (!(valid && f >= 4u)) { st.cur = next; st.pending = false; return 0; }
-
-    // ---------------- match ----------------
-    uint32_t ip = cur;
-    uint32_t lit = cur - st.anchor;
-    if (lit != 0u && cand != 0u) {                           // catch up (search-found matches only)
-        const uint32_t t = x & 0xFFu;
-        const uint32_t eq = t ? ((uint32_t)__builtin_clz(t << 24) >> 1) : 4u;
-        uint32_t b = eq < lit ? eq : lit;
-        b = b < cand ? b : cand;
-        ip -= b; cand -= b; lit -= b;
-        if (__builtin_expect(b == 4u, 0)) {
-            while (ip > st.anchor && cand > 0u &&
-                   snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
+        if (L.pos >= L.n) { out[L.out_idx] = L.total + 4u; return true; }      // + end mark
+        if (L.blocks_left-- == 0u) { atomicOr(status, SNK_ST_ITERCAP); return true; }
+        L.blen = L.n - L.pos < SNK_BLOCK ? L.n - L.pos : SNK_BLOCK;
+        L.iend = L.pos + L.blen;
+        if (L.blen < 13u) {                         // always stored raw; table untouched
+            L.total += 4u + L.blen;
+            L.pos = L.iend;
+            continue;
         }
+        if (!L.first) {
+            // age the table: entries not written during the block just finished are dead
+            for (uint32_t wi = 0; wi < SNK_FBMWORDS; ++wi) {
+                uint32_t z = ~bm[wi];
+                while (z) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(z);
+                    tbl[wi * 32u + b] = 0;
+                    z &= z - 1u;
+                }
+                bm[wi] = 0u;
+            }
+        }
+        L.first = false;
+        L.base = L.pos;
+        L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
+        {
+            const uint32_t w0 = snk_fetch32(L.s, L.pos);
+            const uint32_t s0 = slot[(w0 >> 8) & 1023u];
+            tbl[s0] = 0;                                              // offset 0 of this block
+            atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
+        }
+        L.cur = L.pos + 1u; L.step = 1u; L.nb = 64u; L.anchor = L.pos; L.op = 0u;
+        L.pending = false; L.in_block = true;
+        if (L.cur >= L.s.lx + 4u) snk_win_init(L.w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, L.cur);
+        L.yflag = L.pos >= L.s.lx + SNK_BLOCK + 8u;
+        return false;
     }
+}
+
+// Rare path of a match: long back-extension, long match, length-extension bytes, output
+// budget, end of block -- liblz4's exact accounting.
+__device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur, uint32_t cand, uint32_t f)
+{
+    const SnkFastSrc &s = L.s;
+    uint32_t ip = cur, lit = cur - L.anchor;
+    while (ip > L.anchor && cand > 0u && snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
     uint32_t e2 = cur + f;
-    if (__builtin_expect(f == 12u, 0)) {                     // long match: keep counting, 16 bases a time
+    if (f == 12u) {                                          // keep counting, 16 bases at a time
         uint32_t bpos = cand + (cur - ip) + 12u;
-        while (e2 < st.mlimit) {
+        while (e2 < L.mlimit) {
             const uint32_t d = snk_fetch32(s, e2 + 4u) ^ snk_fetch32(s, bpos + 4u);
             const uint32_t cnt = d ? ((uint32_t)__builtin_ctz(d) >> 1) : 16u;
             e2 += cnt; bpos += cnt;
             if (cnt < 16u) break;
         }
     }
-    if (e2 > st.mlimit) e2 = st.mlimit;
+    if (e2 > L.mlimit) e2 = L.mlimit;
     const uint32_t mc = e2 - ip - 4u;
-    if (__builtin_expect(lit < 15u && mc < 15u, 1)) {
-        // both limitedOutput checks of liblz4 reduce to the same inequality here
-        if (__builtin_expect(st.op + lit + 9u > st.olimit, 0)) return 2;
-        st.op += lit + 3u;
-    } else {
-        uint32_t op = st.op + 1u;
-        if (op + lit + 8u + lit / 255u > st.olimit) return 2;
+    uint32_t op = L.op + 1u;
+    bool bail = op + lit + 8u + lit / 255u > L.olimit;
+    if (!bail) {
         op += lit + snk_lit_ext(lit) + 2u;
-        if (op + 6u + (mc + 240u) / 255u > st.olimit) return 2;
+        bail = op + 6u + (mc + 240u) / 255u > L.olimit;
         if (mc >= 15u) op += (mc - 15u) / 255u + 1u;
-        st.op = op;
     }
-    st.anchor = e2;
-    st.cur = e2; st.step = 1u; st.nb = 63u; st.pending = true;
-    return e2 >= st.mfl1 ? 1 : 0;
+    if (bail) { L.endcode = 2u; L.mfl1 = 0u; L.step = 1u; return; }
+    L.op = op;
+    L.anchor = e2;
+    L.cur = e2; L.step = 1u; L.nb = 63u; L.pending = true;
+    if (e2 >= L.mfl1) { L.endcode = 1u; L.mfl1 = 0u; }
+}
+
+// One iteration of the flat parse loop = one probe (search probes and post-match probes are the
+// same code).  Returns true when the lane's frame is complete.
+// YONLY: wave-uniform promise that every lane is in a block lying > 64 KiB + 8 past its seam with
+// its reservoir on y, so cursor and candidate windows both come from y.
+// The common path is branch-free (selects); everything rare funnels into two branches.
+template <bool YONLY>
+__device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                              const uint16_t *slot, uint32_t *out, uint32_t *status)
+{
+    const uint32_t cur = L.cur;
+    const uint32_t next = cur + L.step;
+    SnkWin &w = L.w;
+
+    // ---- cursor reservoir: slide by 16 bases when needed, refill always in flight ----
+    uint32_t o = cur - 4u - w.rb;                            // need 0 <= o <= 15
+    {
+        const bool sl = (o - 16u) < 16u;
+        w.r0 = sl ? w.r1 : w.r0;
+        w.r1 = sl ? w.nx : w.r1;
+        w.rb += sl ? 16u : 0u;
+        o -= sl ? 16u : 0u;
+    }
+    bool wslow = false;
+    if (__builtin_expect((next > L.mfl1) | (o > 15u) | (!YONLY && cur > w.lim), 0)) {
+        if (next > L.mfl1)                                   // block end, bail-out, or not started yet
+            return snk_fast_block_step(L, T, tbl, bm, slot, out, status);
+        // long jump / source change / seam: re-seat the reservoir
+        if (cur >= L.s.lx + 4u)                          snk_win_init(w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
+        else if (cur >= 4u && cur + 12u <= L.s.lx)       snk_win_init(w, L.s.arena, L.s.xoff, 0u, L.s.lx - 12u, cur);
+        else                                             { w.lim = 0u; wslow = true; }
+        o = cur - 4u - w.rb;
+    }
+    const uint32_t wc = (!YONLY && wslow) ? snk_fetch32(L.s, cur) : __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
+
+    // ---- table probe: two LDS round trips (slot LUT, then table + bitmap) ----
+    const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
+    uint32_t s2 = slot[(wc >> 4) & 1023u];                   // slot of the 5-mer at cur-2
+    s2 = L.pending ? s2 : (SNK_FSLOTS - 1u);                 // nothing owed: aim the put at the unused slot
+    const uint32_t e = tbl[s1];
+    const uint32_t bw = bm[s1 >> 5];
+    const uint32_t c = cur - L.base;                         // offset in the block, 1..65535
+    const uint32_t bit1 = 1u << (s1 & 31u);
+    const bool iscur = (bw & bit1) != 0u;
+    uint32_t cand = L.base + e - (iscur ? 0u : 65536u);
+    bool valid = iscur | (e > c);
+    // liblz4 puts cur-2 BEFORE it reads the slot of cur: same slot => the candidate is cur-2
+    const bool same = (s2 == s1);
+    cand = same ? cur - 2u : cand;
+    valid |= same;
+    tbl[s2] = (uint16_t)(c - 2u);
+    atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+    tbl[s1] = (uint16_t)c;
+    atomicOr(&bm[s1 >> 5], bit1);
+    const uint32_t s3 = L.nb >> 6;
+    const uint32_t nstep = s3 ? s3 : 1u;
+    cand = valid ? cand : cur;                               // keep the fetch in bounds
+
+    // ---- candidate window: the one global-memory round trip of the probe ----
+    // The reservoir refill is issued right next to it (same address again when nothing slid), so
+    // both loads are in flight together and neither is waited for alone.
+    __builtin_amdgcn_sched_barrier(0);
+    snk_g8 *nxp = L.s.arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2));
+    const uint32_t wd = YONLY ? snk_w32_at(L.s.arena, L.s.yoff, (int32_t)(cand - 4u - L.s.lx))
+                              : snk_fetch32(L.s, cand);
+    w.nx = snk_ld4g(nxp);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t x = wc ^ wd;
+    const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;      // equal bases from cur, 0..12
+    const bool m = valid & (f >= 4u);
+
+    // ---- match bookkeeping, computed for every lane and committed by select ----
+    uint32_t lit = cur - L.anchor;
+    const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;   // equal bases before cur, 0..4
+    uint32_t b = eq < lit ? eq : lit;
+    b = b < cand ? b : cand;
+    lit -= b;
+    uint32_t e2 = cur + f;
+    e2 = e2 < L.mlimit ? e2 : L.mlimit;
+    const uint32_t mc = e2 - (cur - b) - 4u;
+    const uint32_t opn = L.op + lit + 3u;                    // token + literals + offset when no extension bytes
+    const uint32_t big = lit > mc ? lit : mc;
+    // both limitedOutput checks of liblz4 reduce to op + lit + 9 > olimit when lit, mc < 15
+    const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit) | (e2 >= L.mfl1));
+    if (__builtin_expect(rare, 0)) {
+        snk_fast_match_slow(L, cur, cand, f);
+        return false;
+    }
+    L.op = m ? opn : L.op;
+    L.anchor = m ? e2 : L.anchor;
+    L.cur = m ? e2 : next;
+    L.step = m ? 1u : nstep;
+    L.nb = m ? 63u : L.nb + 1u;
+    L.pending = m;
+    return false;
 }
 
 // One chain of the 2-bit kernel.  `lds` = this chain's 1904 bytes, `slot` = the
@@ -266,91 +373,31 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
 {
     uint16_t *tbl = (uint16_t *)lds;
     uint32_t *bm = (uint32_t *)(lds + SNK_FSLOTS * 2u);
-    SnkFastSrc s;
+    SnkFastLane L;
     const uint32_t lx = T.len[job.xi];
     const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
-    const uint32_t n = lx + ly;
-    s.xp = (snk_g8 *)T.packed[job.xi];
-    s.yp = (snk_g8 *)(job.yi >= 0 ? T.packed[job.yi] : T.zero_pad + SNK_PAD);
-    s.lx = lx;
-
-    uint32_t pos, total;
-    const uint32_t spos = T.snap_pos[job.xi];
-    if (job.snap == 0 && spos != 0u) { pos = spos; total = T.snap_out[job.xi]; }
-    else                             { pos = 0u;   total = T.header_bytes; }
-
-    SnkFastState st;
-    st.cur = 0; st.step = 1; st.nb = 64; st.anchor = 0; st.op = 0;
-    st.mfl1 = 0; st.mlimit = 0; st.olimit = 0; st.base = pos; st.pending = false;
-    uint32_t iend = 0, blen = 0;
-    bool in_block = false, first = true;
-    uint32_t guard = n + (n >> 10) + 4096u;     // every iteration advances cur or ends a block
-
-    SnkWin w;
-    w.src = s.xp; w.org = 0u; w.rb = 0x80000000u; w.lim = 0u; w.r0 = w.r1 = w.nx = 0u;
+    L.s.arena = (snk_g8 *)T.packed_arena;
+    L.s.xoff = T.packed_off[job.xi];
+    L.s.yoff = job.yi >= 0 ? T.packed_off[job.yi] : SNK_PAD;         // zero region at the arena start
+    L.s.lx = lx;
+    L.n = lx + ly;
+    L.spos = T.snap_pos[job.xi];
+    L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;
+    if (job.snap == 0 && L.spos != 0u) { L.pos = L.spos; L.total = T.snap_out[job.xi]; }
+    else                               { L.pos = 0u;     L.total = T.header_bytes; }
+    L.blocks_left = (L.n >> 16) + 4u;
+    L.iend = 0; L.blen = 0; L.first = true; L.in_block = false;
+    L.cur = 0; L.step = 1; L.nb = 64; L.anchor = 0; L.op = 0;
+    L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos; L.endcode = 0;     // mfl1 = 0: first iteration opens a block
+    L.pending = false; L.yflag = false;
+    L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u; L.w.r0 = L.w.r1 = L.w.nx = 0u;
 
     for (;;) {
-        if (!in_block) {
-            // ---------------- block transition (once per 64 KiB) ----------------
-            if (job.snap != 0 && pos == spos && spos != 0u) {
-                // prefix snapshot: absolute positions; entries older than one block -> 0 (too far for good)
-                uint32_t *dst = T.snap_fast + (size_t)job.xi * SNK_FSLOTS;
-                for (uint32_t t = 0; t < SNK_FSLOTS; ++t)
-                    dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (pos - 65536u + tbl[t]) : 0u;
-                T.snap_out[job.xi] = total;
-            }
-            if (pos >= n) break;
-            blen = n - pos < SNK_BLOCK ? n - pos : SNK_BLOCK;
-            iend = pos + blen;
-            if (blen < 13u) {                       // always stored raw; table untouched
-                total += 4u + blen;
-                pos = iend;
-                continue;
-            }
-            if (!first) {
-                // age the table: entries not written during the block just finished are dead
-                for (uint32_t wi = 0; wi < SNK_FBMWORDS; ++wi) {
-                    uint32_t z = ~bm[wi];
-                    while (z) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(z);
-                        tbl[wi * 32u + b] = 0;
-                        z &= z - 1u;
-                    }
-                    bm[wi] = 0u;
-                }
-            }
-            first = false;
-            st.base = pos;
-            st.mfl1 = iend - 11u; st.mlimit = iend - 5u; st.olimit = blen - 1u;
-            {
-                const uint32_t w0 = snk_fetch32(s, pos);
-                const uint32_t s0 = slot[(w0 >> 8) & 1023u];
-                tbl[s0] = 0;                                          // offset 0 of this block
-                atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
-            }
-            st.cur = pos + 1u; st.step = 1u; st.nb = 64u; st.anchor = pos; st.op = 0u;
-            st.pending = false; in_block = true;
-        }
-        if (--guard == 0u) { atomicOr(status, SNK_ST_ITERCAP); break; }
-
-        int r;
-        const bool yonly = st.cur >= lx + 65536u + 8u;
-        if (__all(yonly)) r = snk_fast_probe<true>(st, w, s, tbl, bm, slot);
-        else              r = snk_fast_probe<false>(st, w, s, tbl, bm, slot);
-
-        if (__builtin_expect(r != 0, 0)) {
-            uint32_t payload = blen;
-            if (r == 1) {
-                const uint32_t run = iend - st.anchor;
-                if (st.op + run + 1u + (run + 240u) / 255u <= st.olimit)
-                    payload = st.op + 1u + snk_lit_ext(run) + run;
-            }
-            total += 4u + payload;
-            pos = iend;
-            in_block = false;
-        }
+        bool done;
+        if (__all(L.yflag)) done = snk_fast_iter<true>(L, T, tbl, bm, slot, out, status);
+        else                done = snk_fast_iter<false>(L, T, tbl, bm, slot, out, status);
+        if (done) break;
     }
-    out[job.out_idx] = total + 4u;      // end mark
 }
 
 // grid: one workgroup per `lanes*waves` jobs.  dynamic LDS = 2 KiB LUT + 1904 B per chain.
