@@ -238,11 +238,12 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
 
 // Rare path of a match: long back-extension, long match, length-extension bytes, output
 // budget, end of block -- liblz4's exact accounting.
-__device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur, uint32_t cand, uint32_t f)
+__device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur, uint32_t cand, uint32_t f,
+                                                    uint32_t anchor0, uint32_t op0)
 {
     const SnkFastSrc &s = L.s;
-    uint32_t ip = cur, lit = cur - L.anchor;
-    while (ip > L.anchor && cand > 0u && snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
+    uint32_t ip = cur, lit = cur - anchor0;
+    while (ip > anchor0 && cand > 0u && snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
     uint32_t e2 = cur + f;
     if (f == 12u) {                                          // keep counting, 16 bases at a time
         uint32_t bpos = cand + (cur - ip) + 12u;
@@ -255,14 +256,14 @@ __device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur
     }
     if (e2 > L.mlimit) e2 = L.mlimit;
     const uint32_t mc = e2 - ip - 4u;
-    uint32_t op = L.op + 1u;
+    uint32_t op = op0 + 1u;
     bool bail = op + lit + 8u + lit / 255u > L.olimit;
     if (!bail) {
         op += lit + snk_lit_ext(lit) + 2u;
         bail = op + 6u + (mc + 240u) / 255u > L.olimit;
         if (mc >= 15u) op += (mc - 15u) / 255u + 1u;
     }
-    if (bail) { L.endcode = 2u; L.mfl1 = 0u; L.step = 1u; return; }
+    if (bail) { L.endcode = 2u; L.mfl1 = 0u; L.step = 1u; L.cur = cur; L.anchor = anchor0; L.op = op0; return; }
     L.op = op;
     L.anchor = e2;
     L.cur = e2; L.step = 1u; L.nb = 63u; L.pending = true;
@@ -353,7 +354,7 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     // both limitedOutput checks of liblz4 reduce to op + lit + 9 > olimit when lit, mc < 15
     const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit) | (e2 >= L.mfl1));
     if (__builtin_expect(rare, 0)) {
-        snk_fast_match_slow(L, cur, cand, f);
+        snk_fast_match_slow(L, cur, cand, f, L.anchor, L.op);
         return false;
     }
     L.op = m ? opn : L.op;
@@ -363,6 +364,117 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     L.nb = m ? 63u : L.nb + 1u;
     L.pending = m;
     return false;
+}
+
+// The y-only phase as a tight loop (98 % of the probes of a 1 Mbp pair).  Entered when every
+// active lane of the wave has yflag; lanes leave only by finishing their frame.  The body has no
+// divergent branch: rare events are detected per lane, and the wave takes a UNIFORM side exit
+// (__any) to serve them.  The loop is rotated: the slot-LUT reads of the NEXT probe are issued
+// as soon as the match length is known, and this probe's bookkeeping runs in their shadow.
+__device__ __forceinline__ void snk_fast_loop_y(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                                const uint16_t *slot, uint32_t *out, uint32_t *status)
+{
+    SnkWin &w = L.w;
+    snk_g8 *const arena = L.s.arena;
+    const uint32_t ybias = L.s.lx + 4u;          // candidate window of stream position p starts at y base p - ybias
+
+    for (;;) {
+        // ======== head: position the reservoir, serve rare pre-conditions, start the LUT reads ========
+        uint32_t cur, next, o;
+        for (;;) {
+            cur = L.cur;
+            next = cur + L.step;
+            o = cur - 4u - w.rb;
+            // no slide here: after a steady-state trip that slid, w.nx no longer matches w.rb;
+            // any cursor outside the reservoir re-seats it (fresh r0, r1, nx)
+            const bool pre = (next > L.mfl1) | (o > 15u);
+            if (__builtin_expect(!__any(pre), 1)) break;
+            if (pre) {
+                if (next > L.mfl1) {                     // block end / bail-out / block not opened yet
+                    if (snk_fast_block_step(L, T, tbl, bm, slot, out, status)) return;
+                } else {                                 // long jump: re-seat the reservoir on y
+                    snk_win_init(w, arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
+                }
+            }
+        }
+        uint32_t wc = __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
+        uint32_t s1 = slot[(wc >> 8) & 1023u];
+        uint32_t s2 = slot[(wc >> 4) & 1023u];
+
+        // ======== steady state: one probe per trip, LUT reads for the next one already in flight ========
+        for (;;) {
+            s2 = L.pending ? s2 : (SNK_FSLOTS - 1u);
+            const uint32_t e = tbl[s1];
+            const uint32_t bw = bm[s1 >> 5];
+            const uint32_t c = cur - L.base;
+            const uint32_t bit1 = 1u << (s1 & 31u);
+            tbl[s2] = (uint16_t)(c - 2u);
+            atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+            tbl[s1] = (uint16_t)c;
+            atomicOr(&bm[s1 >> 5], bit1);
+            const bool iscur = (bw & bit1) != 0u;
+            uint32_t cand = L.base + e - (iscur ? 0u : 65536u);
+            bool valid = iscur | (e > c);
+            const bool same = (s2 == s1);
+            cand = same ? cur - 2u : cand;
+            valid |= same;
+            cand = valid ? cand : cur;
+
+            __builtin_amdgcn_sched_barrier(0);
+            snk_g8 *nxp = arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2));
+            const uint32_t wd = snk_w32_at(arena, L.s.yoff, (int32_t)(cand - ybias));
+            w.nx = snk_ld4g(nxp);
+            __builtin_amdgcn_sched_barrier(0);
+
+            const uint32_t x = wc ^ wd;
+            const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;
+            const bool m = valid & (f >= 4u);
+            uint32_t e2 = cur + f;
+            e2 = e2 < L.mlimit ? e2 : L.mlimit;
+            const uint32_t s3 = L.nb >> 6;
+            const uint32_t nstep = m ? 1u : (s3 ? s3 : 1u);
+            const uint32_t ncur = m ? e2 : next;
+
+            // ---- next probe: reservoir + LUT reads (issued before this probe's bookkeeping) ----
+            const uint32_t nnext = ncur + nstep;
+            uint32_t no = ncur - 4u - w.rb;
+            const bool sl = (no - 16u) < 16u;
+            // NOTE: w.nx was just re-issued; the value consumed by a slide here is the one loaded
+            // during the previous trip only if no slide happened then -- so slide from registers
+            // that are complete: the refill above is waited for together with wd.
+            const uint32_t r0n = sl ? w.r1 : w.r0;
+            const uint32_t r1n = sl ? w.nx : w.r1;
+            no -= sl ? 16u : 0u;
+            const uint32_t nwc = __builtin_amdgcn_alignbit(r1n, r0n, 2u * (no & 15u));
+            const uint32_t ns1 = slot[(nwc >> 8) & 1023u];
+            const uint32_t ns2 = slot[(nwc >> 4) & 1023u];
+
+            // ---- bookkeeping of this probe, in the shadow of the LUT reads ----
+            const uint32_t anchor0 = L.anchor, op0 = L.op;
+            uint32_t lit = cur - anchor0;
+            const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;
+            uint32_t b = eq < lit ? eq : lit;
+            b = b < cand ? b : cand;
+            lit -= b;
+            const uint32_t mc = e2 - (cur - b) - 4u;
+            const uint32_t opn = op0 + lit + 3u;
+            const uint32_t big = lit > mc ? lit : mc;
+            const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit) | (e2 >= L.mfl1));
+            L.op = m ? opn : op0;
+            L.anchor = m ? e2 : anchor0;
+            L.cur = ncur;
+            L.step = nstep;
+            L.nb = m ? 63u : L.nb + 1u;
+            L.pending = m;
+            w.r0 = r0n; w.r1 = r1n; w.rb += sl ? 16u : 0u;
+            const bool pre = (nnext > L.mfl1) | (no > 15u);
+            if (__builtin_expect(__any(rare | pre), 0)) {
+                if (rare) snk_fast_match_slow(L, cur, cand, f, anchor0, op0);
+                break;                                   // back to the head: it re-derives everything from L
+            }
+            cur = ncur; next = nnext; wc = nwc; s1 = ns1; s2 = ns2;
+        }
+    }
 }
 
 // One chain of the 2-bit kernel.  `lds` = this chain's 1904 bytes, `slot` = the
@@ -393,10 +505,11 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u; L.w.r0 = L.w.r1 = L.w.nx = 0u;
 
     for (;;) {
-        bool done;
-        if (__all(L.yflag)) done = snk_fast_iter<true>(L, T, tbl, bm, slot, out, status);
-        else                done = snk_fast_iter<false>(L, T, tbl, bm, slot, out, status);
-        if (done) break;
+        if (__all(L.yflag)) {                       // every active lane is deep inside y: tight loop to the end
+            snk_fast_loop_y(L, T, tbl, bm, slot, out, status);
+            break;
+        }
+        if (snk_fast_iter<false>(L, T, tbl, bm, slot, out, status)) break;
     }
 }
 
