@@ -113,7 +113,12 @@ def main():
     # row shard of this rank (weak scaling: every rank does R rows per step from its own shard)
     rows_per_rank = N // world
     shard0 = rank * rows_per_rank
-    stream = torch.cuda.current_stream()
+    # An explicit (non-default) torch stream: its handle is what the C-ABI launches on, and it is the
+    # current stream for the RCCL all-gather, so the collective is ordered after the kernel.  (The
+    # default stream's handle is 0, which the C-ABI reads as "use the context's own stream".)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     tile = torch.zeros((R, N), dtype=torch.int32, device=dev)     # u32 sizes, viewed as int32
     gathered = torch.zeros((world * R, N), dtype=torch.int32, device=dev) if world > 1 else None
 

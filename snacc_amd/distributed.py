@@ -57,10 +57,12 @@ def all_pairs_hip(ctx, n, group=None):
 
     def rows_fn(r0, r1):
         out = torch.zeros((max(r1 - r0, 0), n), dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()      # the fill must land before another stream writes
         if r1 > r0:
-            stream = torch.cuda.current_stream(dev)
-            ctx.pairs_device(r0, r1, out.data_ptr(), stream.cuda_stream)
-            ctx.sync(stream.cuda_stream)
+            # launch on the context's own stream (NULL) and wait for it: the tile is complete
+            # before the collective is enqueued on torch's stream
+            ctx.pairs_device(r0, r1, out.data_ptr(), None)
+            ctx.sync(None)
         return out
 
     return all_pairs_sharded(n, rows_fn, group=group, device=dev)
