@@ -366,36 +366,64 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     return false;
 }
 
-// The y-only phase as a tight loop (98 % of the probes of a 1 Mbp pair).  Entered when every
-// active lane of the wave has yflag; lanes leave only by finishing their frame.  The body has no
-// divergent branch: rare events are detected per lane, and the wave takes a UNIFORM side exit
-// (__any) to serve them.  The loop is rotated: the slot-LUT reads of the NEXT probe are issued
-// as soon as the match length is known, and this probe's bookkeeping runs in their shadow.
-__device__ __forceinline__ void snk_fast_loop_y(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
-                                                const uint16_t *slot, uint32_t *out, uint32_t *status)
+// Candidate window for the seam-aware tight loop, branch-free: one window from x and one from y
+// are always in flight together and combined by selects (a straddling window is x's zero-padded
+// tail OR-ed with y's head shifted into place).
+__device__ __forceinline__ uint32_t snk_fetch32_nobranch(const SnkFastSrc &s, uint32_t p)
+{
+    const int32_t q0 = (int32_t)p - 4;
+    const bool inx = (p + 12u <= s.lx);
+    const bool iny = (q0 >= (int32_t)s.lx);
+    const uint32_t xv = snk_w32_at(s.arena, s.xoff, iny ? 0 : q0);
+    const uint32_t yv = snk_w32_at(s.arena, s.yoff, iny ? q0 - (int32_t)s.lx : 0);
+    const uint32_t sh = 2u * (uint32_t)((int32_t)s.lx - q0);        // 2..30 when straddling
+    const uint32_t mix = xv | (yv << (sh & 31u));
+    return iny ? yv : (inx ? xv : mix);
+}
+
+#define SNK_LOOP_DONE   0
+#define SNK_LOOP_SWITCH 1
+
+// The parse as a tight loop.  The body has no divergent branch: rare events are detected per lane
+// and the wave takes a UNIFORM side exit (__any) to serve them.  The loop is rotated: the slot-LUT
+// reads of the NEXT probe are issued as soon as the match length is known, and this probe's
+// bookkeeping runs in their shadow.
+//   YONLY = true : every active lane's block lies > 64 KiB + 8 past its seam and its reservoir is
+//                  on y (98 % of the probes of a 1 Mbp pair); lanes leave only by finishing.
+//   YONLY = false: seam-aware candidate fetch; lanes whose reservoir cannot serve the cursor (seam,
+//                  stream start) are stepped by the general one-probe routine in the side exit.
+//                  Returns SNK_LOOP_SWITCH (wave-uniform) once every active lane has yflag.
+// Invariant at the head: w.nx holds the bases [rb+32, rb+48).
+template <bool YONLY>
+__device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                             const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
     SnkWin &w = L.w;
     snk_g8 *const arena = L.s.arena;
     const uint32_t ybias = L.s.lx + 4u;          // candidate window of stream position p starts at y base p - ybias
 
     for (;;) {
-        // ======== head: position the reservoir, serve rare pre-conditions, start the LUT reads ========
+        // ======== head: serve rare pre-conditions, then start the LUT reads ========
         uint32_t cur, next, o;
         for (;;) {
             cur = L.cur;
             next = cur + L.step;
             o = cur - 4u - w.rb;
-            // no slide here: after a steady-state trip that slid, w.nx no longer matches w.rb;
-            // any cursor outside the reservoir re-seats it (fresh r0, r1, nx)
-            const bool pre = (next > L.mfl1) | (o > 15u);
+            const bool pre = (next > L.mfl1) | (o > 15u) | (!YONLY && cur > w.lim);
             if (__builtin_expect(!__any(pre), 1)) break;
             if (pre) {
-                if (next > L.mfl1) {                     // block end / bail-out / block not opened yet
-                    if (snk_fast_block_step(L, T, tbl, bm, slot, out, status)) return;
-                } else {                                 // long jump: re-seat the reservoir on y
-                    snk_win_init(w, arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
+                if (YONLY) {
+                    if (next > L.mfl1) {                 // block end / bail-out
+                        if (snk_fast_block_step(L, T, tbl, bm, slot, out, status)) return SNK_LOOP_DONE;
+                    } else {                             // long jump: re-seat the reservoir on y
+                        snk_win_init(w, arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
+                    }
+                } else {
+                    // one fully general probe: opens/closes blocks, re-seats the reservoir, walks the seam
+                    if (snk_fast_iter<false>(L, T, tbl, bm, slot, out, status)) return SNK_LOOP_DONE;
                 }
             }
+            if (!YONLY && __all(L.yflag)) return SNK_LOOP_SWITCH;
         }
         uint32_t wc = __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
         uint32_t s1 = slot[(wc >> 8) & 1023u];
@@ -422,7 +450,8 @@ __device__ __forceinline__ void snk_fast_loop_y(SnkFastLane &L, const SnkTables 
 
             __builtin_amdgcn_sched_barrier(0);
             snk_g8 *nxp = arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2));
-            const uint32_t wd = snk_w32_at(arena, L.s.yoff, (int32_t)(cand - ybias));
+            const uint32_t wd = YONLY ? snk_w32_at(arena, L.s.yoff, (int32_t)(cand - ybias))
+                                      : snk_fetch32_nobranch(L.s, cand);
             w.nx = snk_ld4g(nxp);
             __builtin_amdgcn_sched_barrier(0);
 
@@ -439,10 +468,7 @@ __device__ __forceinline__ void snk_fast_loop_y(SnkFastLane &L, const SnkTables 
             const uint32_t nnext = ncur + nstep;
             uint32_t no = ncur - 4u - w.rb;
             const bool sl = (no - 16u) < 16u;
-            // NOTE: w.nx was just re-issued; the value consumed by a slide here is the one loaded
-            // during the previous trip only if no slide happened then -- so slide from registers
-            // that are complete: the refill above is waited for together with wd.
-            const uint32_t r0n = sl ? w.r1 : w.r0;
+            const uint32_t r0n = sl ? w.r1 : w.r0;       // w.nx (just refilled, waited for with wd)
             const uint32_t r1n = sl ? w.nx : w.r1;
             no -= sl ? 16u : 0u;
             const uint32_t nwc = __builtin_amdgcn_alignbit(r1n, r0n, 2u * (no & 15u));
@@ -459,7 +485,9 @@ __device__ __forceinline__ void snk_fast_loop_y(SnkFastLane &L, const SnkTables 
             const uint32_t mc = e2 - (cur - b) - 4u;
             const uint32_t opn = op0 + lit + 3u;
             const uint32_t big = lit > mc ? lit : mc;
-            const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit) | (e2 >= L.mfl1));
+            // (a match that ends the block needs no special case: the head closes the block from
+            //  the committed op/anchor exactly as liblz4's last-literals does)
+            const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit));
             L.op = m ? opn : op0;
             L.anchor = m ? e2 : anchor0;
             L.cur = ncur;
@@ -467,10 +495,12 @@ __device__ __forceinline__ void snk_fast_loop_y(SnkFastLane &L, const SnkTables 
             L.nb = m ? 63u : L.nb + 1u;
             L.pending = m;
             w.r0 = r0n; w.r1 = r1n; w.rb += sl ? 16u : 0u;
-            const bool pre = (nnext > L.mfl1) | (no > 15u);
+            const bool pre = (nnext > L.mfl1) | (no > 15u) | (!YONLY && ncur > w.lim);
             if (__builtin_expect(__any(rare | pre), 0)) {
                 if (rare) snk_fast_match_slow(L, cur, cand, f, anchor0, op0);
-                break;                                   // back to the head: it re-derives everything from L
+                // restore the head invariant: the reservoir may just have slid
+                w.nx = snk_ld4g(arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2)));
+                break;                                   // the head re-derives everything from L
             }
             cur = ncur; next = nnext; wc = nwc; s1 = ns1; s2 = ns2;
         }
@@ -505,11 +535,10 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u; L.w.r0 = L.w.r1 = L.w.nx = 0u;
 
     for (;;) {
-        if (__all(L.yflag)) {                       // every active lane is deep inside y: tight loop to the end
-            snk_fast_loop_y(L, T, tbl, bm, slot, out, status);
-            break;
-        }
-        if (snk_fast_iter<false>(L, T, tbl, bm, slot, out, status)) break;
+        int r;
+        if (__all(L.yflag)) r = snk_fast_loop<true>(L, T, tbl, bm, slot, out, status);    // deep inside y, to the end
+        else                r = snk_fast_loop<false>(L, T, tbl, bm, slot, out, status);   // seam-aware
+        if (r == SNK_LOOP_DONE) break;
     }
 }
 
