@@ -51,6 +51,9 @@ def lib():
         L.snk_oracle_pairs_mt.restype = ctypes.c_int
         L.snk_oracle_pairs_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.snk_oracle_pairs_list_mt.restype = ctypes.c_int
+        L.snk_oracle_pairs_list_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                               ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -111,4 +114,17 @@ def pairs_mt(seqs, r0, r1, nthreads):
     rc = lib().snk_oracle_pairs_mt(ptrs, lens, n, r0, r1, out.ctypes.data, nthreads)
     if rc != 0:
         raise RuntimeError("snk_oracle_pairs_mt failed")
+    return out
+
+
+def pairs_list_mt(seqs, ij, nthreads):
+    """Frame sizes of the ordered pairs listed in ij (shape (P, 2)) -- multi-threaded."""
+    arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+    n = len(arrs)
+    ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
+    ij = np.ascontiguousarray(ij, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros(len(ij), dtype=np.uint32)
+    if lib().snk_oracle_pairs_list_mt(ptrs, lens, ij.ctypes.data, len(ij), out.ctypes.data, nthreads) != 0:
+        raise RuntimeError("snk_oracle_pairs_list_mt failed")
     return out

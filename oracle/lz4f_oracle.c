@@ -335,3 +335,40 @@ int snk_oracle_pairs_mt(const uint8_t *const *seqs, const uint64_t *lens, int n,
     free(th); free(jobs);
     return 0;
 }
+
+/* Frame sizes of an arbitrary list of ordered pairs ij[2t], ij[2t+1] (tests: random samples of
+ * the full-size matrix). */
+typedef struct {
+    const uint8_t *const *seqs; const uint64_t *lens; const int32_t *ij; long n_pairs;
+    uint32_t *out; int tid, nthreads;
+} list_job;
+
+static void *list_worker(void *arg)
+{
+    list_job *j = (list_job *)arg;
+    long k;
+    for (k = j->tid; k < j->n_pairs; k += j->nthreads) {
+        int a = j->ij[2 * k], b = j->ij[2 * k + 1];
+        j->out[k] = (uint32_t)snk_oracle_lz4f_size_pair(j->seqs[a], j->lens[a], j->seqs[b], j->lens[b]);
+    }
+    return NULL;
+}
+
+int snk_oracle_pairs_list_mt(const uint8_t *const *seqs, const uint64_t *lens, const int32_t *ij,
+                             long n_pairs, uint32_t *out, int nthreads)
+{
+    pthread_t *th;
+    list_job *jobs;
+    int t;
+    if (nthreads < 1) nthreads = 1;
+    th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    jobs = (list_job *)malloc(sizeof(list_job) * nthreads);
+    if (!th || !jobs) return -1;
+    for (t = 0; t < nthreads; t++) {
+        jobs[t] = (list_job){ seqs, lens, ij, n_pairs, out, t, nthreads };
+        pthread_create(&th[t], NULL, list_worker, &jobs[t]);
+    }
+    for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+    return 0;
+}

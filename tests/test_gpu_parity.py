@@ -185,3 +185,43 @@ def test_full_size_1mbp_properties(hip, golden, oracle_mod):
     assert np.array_equal(m, m.T)
     assert m[0, 1] == 0.999350356687629 and m[0, 0] == 1.000420899139182
     assert abs(m[3, 8] - compute_distance(int(s[3]) + 33, int(s[8]) + 33, int(p[3, 8]) + 33, int(p[8, 3]) + 33)) <= 1e-6
+
+
+def _threads():
+    import os
+    return max(1, min(len(os.sched_getaffinity(0)), 32))
+
+
+def test_config2_full_matrix_256x100kbp(hip, oracle_mod):
+    """BASELINE.json configs[1]: all 65 536 ordered pairs + 256 singles of 256 x 100 kbp genomes,
+    every size compared with the oracle."""
+    from oracle.loader import pairs_mt
+    n, L = 256, 100_000
+    seqs = [oracle_mod.lcg_genome(1 + i, L) for i in range(n)]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        s, p = ctx.singles(), ctx.pairs()
+    assert np.array_equal(s, np.array([oracle_mod.lz4f_size(x) for x in seqs], dtype=np.uint32))
+    assert np.array_equal(p, pairs_mt(seqs, 0, n, _threads()))
+
+
+def test_config3_sample_1024x1mbp(hip, oracle_mod):
+    """BASELINE.json configs[2] at full size: the whole 1024 x 1024 matrix on the GPU; first row,
+    first column, diagonal and a >= 1 % uniform sample of the pairs checked against the oracle."""
+    from oracle.loader import pairs_list_mt
+    n, L = 1024, 1_000_000
+    seqs = [oracle_mod.lcg_genome(1 + i, L) for i in range(n)]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        s, p = ctx.singles(), ctx.pairs()
+    rng = np.random.default_rng(2026)
+    idx = np.arange(n)
+    ij = np.concatenate([np.stack([np.zeros(n, int), idx], 1), np.stack([idx, np.zeros(n, int)], 1),
+                         np.stack([idx, idx], 1), rng.integers(0, n, (10600, 2))])
+    want = pairs_list_mt(seqs, ij, _threads())
+    assert np.array_equal(p[ij[:, 0], ij[:, 1]], want)
+    for g in (0, 1, 511, 1023):
+        assert int(s[g]) == oracle_mod.lz4f_size(seqs[g])
+    from snacc_amd.matrix import ncd_matrix
+    m = ncd_matrix(s.astype(np.int64) + 33, p.astype(np.int64) + 33)
+    assert np.array_equal(m, m.T) and m[0, 1] == 0.999350356687629
