@@ -25,7 +25,8 @@ struct snk_ctx_impl {
     std::string err;
 
     // options
-    int fast_lanes = 21, fast_waves = 4, gen_chains = 8;
+    int fast_lanes = 21, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;
+    bool bytes_legacy = false;      // 1 = linked-mode byte jobs also go to the legacy u32-table kernel
     bool force_generic = false;
     uint32_t header_bytes = 7;
 
@@ -34,7 +35,7 @@ struct snk_ctx_impl {
     std::vector<uint32_t> len;
     std::vector<uint8_t> is_packed;
     uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_zero = nullptr;
-    const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr;
+    const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
     uint16_t *d_lut_slot = nullptr; uint32_t *d_lut_hash = nullptr;
@@ -70,7 +71,7 @@ template <typename T> void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p =
 
 void free_sequences(snk_ctx_impl *c)
 {
-    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off);
+    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast);
     dfree(c->d_snap_gen); dfree(c->d_single);
     c->n = 0; c->n_packed = 0; c->len.clear(); c->is_packed.clear(); c->singles_done = false;
@@ -105,7 +106,7 @@ bool build_luts(std::vector<uint16_t> &slot, std::vector<uint32_t> &hash)
 SnkTables make_tables(const snk_ctx_impl *c)
 {
     SnkTables T;
-    T.bytes = c->d_bytes_ptr; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
+    T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
     T.lut_slot = c->d_lut_slot; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
@@ -127,9 +128,8 @@ int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
     return SNK_OK;
 }
 
-// Launch both kernels over a job list.  jobs[0 .. n_fast) go to the 2-bit kernel,
-// jobs[n_fast .. n_fast+n_gen) to the byte kernel.  `d_jobs` already on device.
-int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_fast, size_t n_gen,
+// Launch the kernels over a job list laid out as [2-bit jobs | linked byte jobs | one-shot jobs].
+int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_fast, size_t n_bytes, size_t n_gen,
                 uint32_t *d_out)
 {
     SnkTables T = make_tables(c);
@@ -146,6 +146,19 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                            T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
+    if (n_bytes) {
+        const uint32_t lanes = (uint32_t)c->bytes_lanes, waves = (uint32_t)c->bytes_waves;
+        const uint32_t chains = lanes * waves;
+        const size_t lds = (size_t)chains * SNK_BCHAIN_B;
+        if (lds > 160 * 1024)
+            return fail(c, SNK_E_ARG, "bytes_lanes*bytes_waves = %u chains exceed the 160 KiB LDS (max 18)", chains);
+        HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t grid = (uint32_t)((n_bytes + chains - 1) / chains);
+        hipLaunchKernelGGL(snk_bytes_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                           T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        HIPCHK(c, hipGetLastError());
+    }
     if (n_gen) {
         const uint32_t chains = (uint32_t)c->gen_chains;
         const size_t lds = (size_t)chains * 16384;
@@ -153,7 +166,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t grid = (uint32_t)((n_gen + chains - 1) / chains);
         hipLaunchKernelGGL(snk_generic_kernel, dim3(grid), dim3(64), lds, st,
-                           T, d_jobs + n_fast, (uint32_t)n_gen, chains, d_out, c->d_status);
+                           T, d_jobs + n_fast + n_bytes, (uint32_t)n_gen, chains, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
     return SNK_OK;
@@ -180,32 +193,35 @@ bool pair_is_fast(const snk_ctx_impl *c, int i, int j)
 // Fast jobs are ordered by suffix sequence j so that the chains of one workgroup
 // walk the same bytes (L1/L2 locality); generic jobs follow.
 template <typename PairAt>
-int build_jobs(snk_ctx_impl *c, size_t n_pairs, PairAt pair_at, size_t &n_fast, size_t &n_gen)
+int build_jobs(snk_ctx_impl *c, size_t n_pairs, PairAt pair_at, size_t &n_fast, size_t &n_bytes, size_t &n_gen)
 {
-    std::vector<SnkJob> fast, gen;
+    std::vector<SnkJob> fast, bytes, gen;
     fast.reserve(n_pairs);
     for (size_t t = 0; t < n_pairs; ++t) {
         int i, j; uint32_t o;
         pair_at(t, i, j, o);
         if (i < 0 || j < 0 || i >= c->n || j >= c->n) return fail(c, SNK_E_ARG, "pair index out of range");
-        if ((uint64_t)c->len[i] + c->len[j] >= 0x7E000000ull)
-            return fail(c, SNK_E_TOOBIG, "concatenation of %d and %d too long", i, j);
+        const uint64_t n = (uint64_t)c->len[i] + c->len[j];
+        if (n >= 0x7E000000ull) return fail(c, SNK_E_TOOBIG, "concatenation of %d and %d too long", i, j);
         SnkJob jb; jb.xi = i; jb.yi = j; jb.out_idx = o; jb.snap = 0;
-        (pair_is_fast(c, i, j) ? fast : gen).push_back(jb);
+        if (pair_is_fast(c, i, j)) fast.push_back(jb);
+        else if (n > SNK_BLOCK && !c->bytes_legacy) bytes.push_back(jb);
+        else gen.push_back(jb);
     }
-    n_fast = fast.size(); n_gen = gen.size();
+    n_fast = fast.size(); n_bytes = bytes.size(); n_gen = gen.size();
     c->h_jobs.swap(fast);
+    c->h_jobs.insert(c->h_jobs.end(), bytes.begin(), bytes.end());
     c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
     return SNK_OK;
 }
 
-int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_gen, uint32_t *d_out)
+int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_bytes, size_t n_gen, uint32_t *d_out)
 {
-    const size_t nj = n_fast + n_gen;
+    const size_t nj = n_fast + n_bytes + n_gen;
     if (nj == 0) return SNK_OK;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), nj * sizeof(SnkJob), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
-    int rc = launch_jobs(c, st, c->d_jobs, n_fast, n_gen, d_out);
+    int rc = launch_jobs(c, st, c->d_jobs, n_fast, n_bytes, n_gen, d_out);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, st));
     c->ev_valid = true;
@@ -299,6 +315,14 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "gen_chains") {
         if (value < 1 || value > 9) return fail(c, SNK_E_ARG, "gen_chains must be 1..9");
         c->gen_chains = (int)value;
+    } else if (k == "bytes_lanes") {
+        if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "bytes_lanes must be 1..64");
+        c->bytes_lanes = (int)value;
+    } else if (k == "bytes_waves") {
+        if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "bytes_waves must be 1..16");
+        c->bytes_waves = (int)value;
+    } else if (k == "bytes_legacy") {
+        c->bytes_legacy = value != 0;
     } else if (k == "force_generic") {
         c->force_generic = value != 0;
     } else if (k == "content_size") {
@@ -331,6 +355,8 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     }
     c->len.resize(n);
     for (size_t g = 0; g < n; ++g) c->len[g] = (uint32_t)lens[g];
+    if (btot >= 0xFFF00000ull)
+        return fail(c, SNK_E_TOOBIG, "ASCII arena of %zu bytes exceeds the 4 GiB offset range", btot);
 
     HIPCHK(c, hipMalloc((void **)&c->d_bytes, btot));
     HIPCHK(c, hipMemsetAsync(c->d_bytes, 0, btot, c->stream));
@@ -376,15 +402,16 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipGetLastError());
 
     // ---- per-sequence tables ------------------------------------------------------------------
-    std::vector<const uint8_t *> bp(n); std::vector<uint32_t> pp(n);
+    std::vector<const uint8_t *> bp(n); std::vector<uint32_t> pp(n), bo(n);
     std::vector<uint32_t> spos(n);
     for (size_t g = 0; g < n; ++g) {
-        bp[g] = c->d_bytes + boff[g];
+        bp[g] = c->d_bytes + boff[g]; bo[g] = (uint32_t)boff[g];
         pp[g] = c->is_packed[g] ? (uint32_t)poff[g] : 0u;
         spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
     }
     HIPCHK(c, hipMalloc((void **)&c->d_bytes_ptr, n * sizeof(void *)));
     HIPCHK(c, hipMalloc((void **)&c->d_packed_off, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_bytes_off, n * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&c->d_len, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_pos, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->d_snap_out, n * 4));
@@ -393,27 +420,30 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipMalloc((void **)&c->d_snap_gen, n * 4096 * 4));
     HIPCHK(c, hipMemcpy(c->d_bytes_ptr, bp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_packed_off, pp.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_bytes_off, bo.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_len, c->len.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_snap_pos, spos.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->d_snap_out, 0, n * 4, c->stream));
     c->n = n_seq;
 
     // ---- singles + snapshots (phase A) --------------------------------------------------------
-    std::vector<SnkJob> fast, gen;
+    std::vector<SnkJob> fast, bytes, gen;
     std::vector<uint32_t> conv;
     for (size_t g = 0; g < n; ++g) {
         SnkJob jb; jb.xi = (int)g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
         const bool f = !c->force_generic && c->is_packed[g] && lens[g] > SNK_BLOCK;
-        (f ? fast : gen).push_back(jb);
-        if (f) conv.push_back((uint32_t)g);
+        if (f) { fast.push_back(jb); conv.push_back((uint32_t)g); }
+        else if (lens[g] > SNK_BLOCK && !c->bytes_legacy) bytes.push_back(jb);
+        else gen.push_back(jb);
     }
-    const size_t nf = fast.size(), ng = gen.size();
+    const size_t nf = fast.size(), nb = bytes.size(), ng = gen.size();
     c->h_jobs = fast;
+    c->h_jobs.insert(c->h_jobs.end(), bytes.begin(), bytes.end());
     c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
     int rc = ensure_scratch(c, n, 0);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), n * sizeof(SnkJob), hipMemcpyHostToDevice, c->stream));
-    rc = launch_jobs(c, c->stream, c->d_jobs, nf, ng, c->d_single);
+    rc = launch_jobs(c, c->stream, c->d_jobs, nf, nb, ng, c->d_single);
     if (rc) return rc;
     if (!conv.empty()) {
         uint32_t *d_ids = nullptr;
@@ -451,16 +481,16 @@ int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const size_t N = (size_t)c->n, np = (size_t)(r1 - r0) * N;
     if (!np) return SNK_OK;
-    size_t nf = 0, ng = 0;
+    size_t nf = 0, nb = 0, ng = 0;
     // order: suffix j outer, prefix i inner => the chains of a workgroup share seq_j
     int rc = build_jobs(c, np, [&](size_t t, int &i, int &j, uint32_t &o) {
         j = (int)(t / (size_t)(r1 - r0)); i = r0 + (int)(t % (size_t)(r1 - r0));
         o = (uint32_t)((size_t)(i - r0) * N + (size_t)j);
-    }, nf, ng);
+    }, nf, nb, ng);
     if (rc) return rc;
     rc = ensure_scratch(c, np, 0);
     if (rc) return rc;
-    return run_pairs(c, st, nf, ng, (uint32_t *)d_sizes);
+    return run_pairs(c, st, nf, nb, ng, (uint32_t *)d_sizes);
 }
 
 int snk_sync(snk_ctx *c, void *hip_stream)
@@ -493,18 +523,18 @@ int snk_pairs_list(snk_ctx *c, int n_pairs, const int32_t *ij, uint32_t *sizes)
     if (!c->singles_done) return fail(c, SNK_E_STATE, "snk_upload has not completed");
     if (!n_pairs) return SNK_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    size_t nf = 0, ng = 0;
+    size_t nf = 0, nb = 0, ng = 0;
     // sort by suffix for locality, keep the caller's output order
     std::vector<uint32_t> order((size_t)n_pairs);
     for (uint32_t t = 0; t < (uint32_t)n_pairs; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ij[2 * a + 1] < ij[2 * b + 1]; });
     int rc = build_jobs(c, (size_t)n_pairs, [&](size_t t, int &i, int &j, uint32_t &o) {
         o = order[t]; i = ij[2 * o]; j = ij[2 * o + 1];
-    }, nf, ng);
+    }, nf, nb, ng);
     if (rc) return rc;
     rc = ensure_scratch(c, (size_t)n_pairs, (size_t)n_pairs);
     if (rc) return rc;
-    rc = run_pairs(c, c->stream, nf, ng, c->d_out);
+    rc = run_pairs(c, c->stream, nf, nb, ng, c->d_out);
     if (rc) return rc;
     rc = snk_sync(c, nullptr);
     if (rc) return rc;

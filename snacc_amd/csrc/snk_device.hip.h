@@ -43,7 +43,9 @@ struct SnkJob {
 
 struct SnkTables {
     // per-sequence, all device pointers
-    const uint8_t  *const *bytes;     // ASCII, padded
+    const uint8_t  *const *bytes;     // ASCII, padded (per-sequence pointers, legacy byte kernel)
+    const uint8_t  *bytes_arena;      // the same ASCII data as one allocation < 4 GiB; starts with SNK_PAD zero bytes
+    const uint32_t *bytes_off;        // byte offset of each sequence in the ASCII arena
     const uint8_t  *packed_arena;     // 2-bit packed sequences, one allocation < 4 GiB; starts with 4*SNK_PAD zero bytes
     const uint32_t *packed_off;       // byte offset of each packed sequence in the arena (0 = not packed)
     const uint32_t *len;
@@ -772,6 +774,388 @@ __global__ void snk_generic_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_j
     __syncthreads();
 
     if (active) snk_gen_chain(T, job, tbl, out, status);
+}
+
+// =========================================================================
+//  byte kernel, linked mode (n > 64 KiB), any alphabet: N runs, lower case, protein ...
+// =========================================================================
+//
+// Same execution model as the 2-bit kernel (one lane = one chain, flat probe loop, side exits
+// that are wave-uniform, cursor-side register reservoir) on ASCII data.  The table is liblz4's
+// full 4096-slot table, kept as 16-bit block offsets + "written this block" bitmap exactly like
+// the 2-bit kernel: 8712 B per chain -> 18 chains per CU (the u32 table of snk_generic_kernel
+// allows 8).  The slot is liblz4's 12-bit hash of 5 bytes, computed arithmetically.
+#define SNK_BSLOTS      4096u
+#define SNK_BDUMMY      4096u                    // extra slot that absorbs the put of "nothing owed"
+#define SNK_BTBL_B      ((SNK_BSLOTS + 2u) * 2u) // 8196
+#define SNK_BBMWORDS    129u
+#define SNK_BCHAIN_B    (SNK_BTBL_B + SNK_BBMWORDS * 4u)   // 8712 bytes
+
+struct SnkByteSrc {
+    snk_g8 *arena;            // wave-uniform base of the ASCII arena
+    uint32_t xoff, yoff;      // byte offsets of the two sequences
+    uint32_t lx;
+};
+
+__device__ __forceinline__ uint32_t snk_hash5_parts(uint32_t a_lo, uint32_t a_hi)
+{
+    // ((seq << 24) * 889523592379) >> 52 with (seq << 24) = a_hi:a_lo
+    const uint64_t a = ((uint64_t)a_hi << 32) | a_lo;
+    return (uint32_t)((a * 889523592379ull) >> 52);
+}
+
+// 8 bytes of the concatenation starting at p, seam aware (slow paths only)
+__device__ __forceinline__ uint64_t snk_bld8(const SnkByteSrc &s, uint32_t p)
+{
+    if (p + 8u <= s.lx) return snk_ld8g(s.arena + (size_t)(s.xoff + p));
+    if (p >= s.lx) return snk_ld8g(s.arena + (size_t)(s.yoff + (p - s.lx)));
+    const uint32_t k = s.lx - p;                               // 1..7 bytes from x, rest from y
+    const uint64_t xv = snk_ld8g(s.arena + (size_t)(s.xoff + p));      // zero beyond lx (padding)
+    const uint64_t yv = snk_ld8g(s.arena + (size_t)s.yoff);
+    return xv | (yv << (8u * k));
+}
+__device__ __forceinline__ uint32_t snk_bbyte(const SnkByteSrc &s, uint32_t p)
+{
+    return p < s.lx ? s.arena[(size_t)(s.xoff + p)] : s.arena[(size_t)(s.yoff + (p - s.lx))];
+}
+
+// Candidate window for the tight loop: bytes [p-1, p+7), branch-free (x and y windows always in
+// flight together; a straddling window is x's zero-padded tail OR y's head shifted into place).
+__device__ __forceinline__ uint64_t snk_bfetch8_nobranch(const SnkByteSrc &s, uint32_t p)
+{
+    const int32_t q0 = (int32_t)p - 1;
+    const bool inx = (p + 7u <= s.lx);
+    const bool iny = (q0 >= (int32_t)s.lx);
+    const uint64_t xv = snk_ld8g(s.arena + (size_t)(uint32_t)((int32_t)s.xoff + (iny ? 0 : q0)));
+    const uint64_t yv = snk_ld8g(s.arena + (size_t)(s.yoff + (iny ? (uint32_t)(q0 - (int32_t)s.lx) : 0u)));
+    const uint32_t k = (uint32_t)((int32_t)s.lx - q0) & 7u;   // 1..7 when straddling
+    const uint64_t mix = xv | (yv << (8u * k));
+    return iny ? yv : (inx ? xv : mix);
+}
+
+// Cursor-side reservoir: 20 bytes [rb, rb+20) of ONE source in registers plus the next 8 in
+// flight.  A probe at cur needs bytes [cur-2, cur+10): offset o = cur-2-rb must be 0..7.
+struct SnkBWin {
+    uint32_t soff, org, rb, lim;       // lim = largest cursor this source can serve (0 = unusable)
+    uint32_t r0, r1, r2, r3, r4, nx0, nx1;
+};
+
+__device__ __forceinline__ void snk_bwin_init(SnkBWin &w, snk_g8 *arena, uint32_t soff, uint32_t org,
+                                              uint32_t lim, uint32_t cur)
+{
+    w.soff = soff; w.org = org; w.lim = lim;
+    w.rb = org + ((cur - 2u - org) & ~3u);
+    snk_g8 *p = arena + (size_t)(soff + (w.rb - org));
+    w.r0 = snk_ld4g(p); w.r1 = snk_ld4g(p + 4); w.r2 = snk_ld4g(p + 8); w.r3 = snk_ld4g(p + 12);
+    w.r4 = snk_ld4g(p + 16); w.nx0 = snk_ld4g(p + 20); w.nx1 = snk_ld4g(p + 24);
+}
+
+struct SnkByteLane {
+    SnkByteSrc s;
+    uint32_t n, spos;
+    int32_t xi, snap;
+    uint32_t out_idx;
+    uint32_t pos, total, iend, blen, blocks_left;
+    bool first, in_block;
+    uint32_t cur, step, nb, anchor, op;
+    uint32_t mfl1, mlimit, olimit, base;
+    uint32_t endcode;
+    bool pending;
+    SnkBWin w;
+};
+
+// Data of one probe taken from the reservoir at byte offset o (0..7): the compare window
+// [cur-1, cur+7) and the two table slots (5-mers at cur and at cur-2).
+struct SnkBProbeData { uint32_t wlo, whi, s1, s2; };
+
+__device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t o)
+{
+    const bool hi = (o & 4u) != 0u;
+    const uint32_t sh = (o & 3u) * 8u;
+    const uint32_t a0 = hi ? w.r1 : w.r0, a1 = hi ? w.r2 : w.r1, a2 = hi ? w.r3 : w.r2, a3 = hi ? w.r4 : w.r3;
+    const uint32_t e0 = __builtin_amdgcn_alignbit(a1, a0, sh);       // bytes cur-2 .. cur+1
+    const uint32_t e1 = __builtin_amdgcn_alignbit(a2, a1, sh);       // bytes cur+2 .. cur+5
+    const uint32_t e2 = __builtin_amdgcn_alignbit(a3, a2, sh);       // bytes cur+6 .. cur+9
+    SnkBProbeData d;
+    d.wlo = __builtin_amdgcn_alignbit(e1, e0, 8);                    // bytes cur-1 .. cur+2
+    d.whi = __builtin_amdgcn_alignbit(e2, e1, 8);                    // bytes cur+3 .. cur+6
+    d.s2 = snk_hash5_parts(e0 << 24, __builtin_amdgcn_alignbit(e1, e0, 8));               // 5 bytes at cur-2
+    d.s1 = snk_hash5_parts((e0 << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(e1, e0, 24)); // 5 bytes at cur
+    return d;
+}
+
+__device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                                     uint32_t *out, uint32_t *status)
+{
+    if (L.in_block) {
+        uint32_t payload = L.blen;
+        if (L.endcode != 2u) {
+            const uint32_t run = L.iend - L.anchor;
+            if (L.op + run + 1u + (run + 240u) / 255u <= L.olimit)
+                payload = L.op + 1u + snk_lit_ext(run) + run;
+        }
+        L.total += 4u + payload;
+        L.pos = L.iend;
+        L.in_block = false;
+        L.endcode = 0u;
+    }
+    for (;;) {
+        if (L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
+            uint32_t *dst = T.snap_gen + (size_t)L.xi * 4096u;
+            for (uint32_t t = 0; t < SNK_BSLOTS; ++t)
+                dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.pos - 65536u + tbl[t]) : 0u;
+            T.snap_out[L.xi] = L.total;
+        }
+        if (L.pos >= L.n) { out[L.out_idx] = L.total + 4u; return true; }
+        if (L.blocks_left-- == 0u) { atomicOr(status, SNK_ST_ITERCAP); return true; }
+        L.blen = L.n - L.pos < SNK_BLOCK ? L.n - L.pos : SNK_BLOCK;
+        L.iend = L.pos + L.blen;
+        if (L.blen < 13u) { L.total += 4u + L.blen; L.pos = L.iend; continue; }
+        if (!L.first) {
+            for (uint32_t wi = 0; wi < SNK_BSLOTS / 32u; ++wi) {
+                uint32_t z = ~bm[wi];
+                while (z) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(z);
+                    tbl[wi * 32u + b] = 0;
+                    z &= z - 1u;
+                }
+                bm[wi] = 0u;
+            }
+        }
+        L.first = false;
+        L.base = L.pos;
+        L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
+        {
+            const uint64_t w0 = snk_bld8(L.s, L.pos);
+            const uint32_t s0 = snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
+            tbl[s0] = 0;
+            atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
+        }
+        L.cur = L.pos + 1u; L.step = 1u; L.nb = 64u; L.anchor = L.pos; L.op = 0u;
+        L.pending = false; L.in_block = true;
+        return false;
+    }
+}
+
+// liblz4's exact handling of a match found at cur with candidate cand (slow, general).
+__device__ __forceinline__ void snk_bytes_match_slow(SnkByteLane &L, uint32_t cur, uint32_t cand,
+                                                     uint32_t anchor0, uint32_t op0)
+{
+    const SnkByteSrc &s = L.s;
+    uint32_t ip = cur;
+    while (ip > anchor0 && cand > 0u && snk_bbyte(s, ip - 1u) == snk_bbyte(s, cand - 1u)) { ip--; cand--; }
+    const uint32_t lit = ip - anchor0;
+    uint32_t a = ip + 4u, b = cand + 4u;
+    while (a < L.mlimit) {
+        const uint64_t d = snk_bld8(s, a) ^ snk_bld8(s, b);
+        if (d) { a += (uint32_t)__builtin_ctzll(d) >> 3; break; }
+        a += 8u; b += 8u;
+    }
+    if (a > L.mlimit) a = L.mlimit;
+    const uint32_t mc = a - (ip + 4u);
+    uint32_t op = op0 + 1u;
+    bool bail = op + lit + 8u + lit / 255u > L.olimit;
+    if (!bail) {
+        op += lit + snk_lit_ext(lit) + 2u;
+        bail = op + 6u + (mc + 240u) / 255u > L.olimit;
+        if (mc >= 15u) op += (mc - 15u) / 255u + 1u;
+    }
+    if (bail) { L.endcode = 2u; L.mfl1 = 0u; L.step = 1u; L.cur = cur; L.anchor = anchor0; L.op = op0; return; }
+    L.op = op;
+    L.anchor = a;
+    L.cur = a; L.step = 1u; L.nb = 63u; L.pending = true;
+    if (a >= L.mfl1) { L.endcode = 1u; L.mfl1 = 0u; }
+}
+
+// table probe shared by the slow and the tight paths: returns candidate + validity, performs the puts
+__device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *tbl, uint32_t *bm, uint32_t cur,
+                                                uint32_t s1, uint32_t s2, uint32_t &cand, bool &valid)
+{
+    s2 = L.pending ? s2 : SNK_BDUMMY;
+    const uint32_t e = tbl[s1];
+    const uint32_t bw = bm[s1 >> 5];
+    const uint32_t c = cur - L.base;
+    const uint32_t bit1 = 1u << (s1 & 31u);
+    tbl[s2] = (uint16_t)(c - 2u);
+    atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+    tbl[s1] = (uint16_t)c;
+    atomicOr(&bm[s1 >> 5], bit1);
+    const bool iscur = (bw & bit1) != 0u;
+    cand = L.base + e - (iscur ? 0u : 65536u);
+    valid = iscur | (e > c);
+    const bool same = (s2 == s1);
+    cand = same ? cur - 2u : cand;
+    valid |= same;
+    cand = valid ? cand : cur;
+}
+
+// One fully general probe with direct loads (stream start, seam, after long jumps).
+__device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                                    uint32_t *out, uint32_t *status)
+{
+    const uint32_t cur = L.cur, next = cur + L.step;
+    if (next > L.mfl1) return snk_bytes_block_step(L, T, tbl, bm, out, status);
+    const uint64_t wc = snk_bld8(L.s, cur);
+    const uint64_t wp = snk_bld8(L.s, cur - 2u);               // cur >= 1; at cur == 1 byte -1 is padding (unused: nothing owed)
+    const uint32_t s1 = snk_hash5_parts((uint32_t)wc << 24, (uint32_t)(wc >> 8));
+    const uint32_t s2 = snk_hash5_parts((uint32_t)wp << 24, (uint32_t)(wp >> 8));
+    uint32_t cand; bool valid;
+    snk_bytes_table(L, tbl, bm, cur, s1, s2, cand, valid);
+    const uint32_t s3 = L.nb >> 6;
+    const uint64_t wd = snk_bld8(L.s, cand);
+    if (valid && (uint32_t)wc == (uint32_t)wd) {
+        snk_bytes_match_slow(L, cur, cand, L.anchor, L.op);
+    } else {
+        L.cur = next; L.step = s3 ? s3 : 1u; L.nb++; L.pending = false;
+    }
+    // seat the reservoir for the tight loop when the new cursor allows it
+    const uint32_t nc = L.cur;
+    if (nc >= L.s.lx + 2u)                         snk_bwin_init(L.w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, nc);
+    else if (nc >= 2u && nc + 10u <= L.s.lx)       snk_bwin_init(L.w, L.s.arena, L.s.xoff, 0u, L.s.lx - 10u, nc);
+    else                                           L.w.lim = 0u;
+    return false;
+}
+
+// Tight loop.  Invariant at the head: (nx0, nx1) hold the bytes [rb+20, rb+28).
+__device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                               uint32_t *out, uint32_t *status)
+{
+    SnkBWin &w = L.w;
+    snk_g8 *const arena = L.s.arena;
+    for (;;) {
+        uint32_t cur, next, o;
+        for (;;) {
+            cur = L.cur;
+            next = cur + L.step;
+            o = cur - 2u - w.rb;
+            const bool pre = (next > L.mfl1) | (o > 7u) | (cur > w.lim);
+            if (__builtin_expect(!__any(pre), 1)) break;
+            if (pre && snk_bytes_iter_slow(L, T, tbl, bm, out, status)) return;
+        }
+        SnkBProbeData d = snk_bextract(w, o);
+
+        for (;;) {
+            uint32_t cand; bool valid;
+            snk_bytes_table(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
+
+            __builtin_amdgcn_sched_barrier(0);
+            snk_g8 *nxp = arena + (size_t)(w.soff + (w.rb + 20u - w.org));
+            const uint64_t wd = snk_bfetch8_nobranch(L.s, cand);
+            const uint64_t nxv = snk_ld8g(nxp);
+            __builtin_amdgcn_sched_barrier(0);
+            w.nx0 = (uint32_t)nxv; w.nx1 = (uint32_t)(nxv >> 32);
+
+            const uint32_t xlo = d.wlo ^ (uint32_t)wd, xhi = d.whi ^ (uint32_t)(wd >> 32);
+            // forward equal bytes from cur: bytes 1..7 of the windows
+            const uint32_t f_lo = __builtin_amdgcn_alignbit(xhi, xlo, 8);          // diff of bytes cur .. cur+3
+            const uint32_t f_hi = (xhi >> 8) | 0x01000000u;                         // diff of bytes cur+4 .. cur+6, sentinel
+            const uint32_t f = f_lo ? ((uint32_t)__builtin_ctz(f_lo) >> 3) : 4u + ((uint32_t)__builtin_ctz(f_hi) >> 3);
+            const bool m = valid & (f_lo == 0u);
+            uint32_t e2 = cur + f;
+            e2 = e2 < L.mlimit ? e2 : L.mlimit;
+            const uint32_t s3 = L.nb >> 6;
+            const uint32_t nstep = m ? 1u : (s3 ? s3 : 1u);
+            const uint32_t ncur = m ? e2 : next;
+            const uint32_t nnext = ncur + nstep;
+
+            // ---- next probe's data from the reservoir ----
+            uint32_t no = ncur - 2u - w.rb;
+            const bool sl = (no - 8u) < 8u;                   // slide by 8 bytes
+            const uint32_t r0n = sl ? w.r2 : w.r0, r1n = sl ? w.r3 : w.r1, r2n = sl ? w.r4 : w.r2;
+            const uint32_t r3n = sl ? w.nx0 : w.r3, r4n = sl ? w.nx1 : w.r4;
+            no -= sl ? 8u : 0u;
+            w.r0 = r0n; w.r1 = r1n; w.r2 = r2n; w.r3 = r3n; w.r4 = r4n; w.rb += sl ? 8u : 0u;
+            const SnkBProbeData nd = snk_bextract(w, no & 7u);
+
+            // ---- bookkeeping of this probe ----
+            const uint32_t anchor0 = L.anchor, op0 = L.op;
+            const uint32_t lit = cur - anchor0;
+            const bool backeq = ((xlo & 0xFFu) == 0u) & (lit != 0u) & (cand != 0u);   // catch-up needed
+            const uint32_t mc = e2 - cur - 4u;
+            const uint32_t opn = op0 + lit + 3u;
+            const uint32_t big = lit > mc ? lit : mc;
+            const bool rare = m & (backeq | (f == 7u) | (big >= 15u) | (opn + 6u > L.olimit));
+            L.op = m ? opn : op0;
+            L.anchor = m ? e2 : anchor0;
+            L.cur = ncur;
+            L.step = nstep;
+            L.nb = m ? 63u : L.nb + 1u;
+            L.pending = m;
+            const bool pre = (nnext > L.mfl1) | (no > 7u) | (ncur > w.lim);
+            if (__builtin_expect(__any(rare | pre), 0)) {
+                if (rare) snk_bytes_match_slow(L, cur, cand, anchor0, op0);
+                const uint64_t rf = snk_ld8g(arena + (size_t)(w.soff + (w.rb + 20u - w.org)));
+                w.nx0 = (uint32_t)rf; w.nx1 = (uint32_t)(rf >> 32);
+                break;
+            }
+            cur = ncur; next = nnext; d = nd;
+        }
+    }
+}
+
+// grid: one workgroup per `lanes*waves` jobs; dynamic LDS = 8712 B per chain.
+__global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                 uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t waves = blockDim.x >> 6;
+    const uint32_t chains = lanes * waves;
+    const uint32_t c = lane * waves + wave;
+    const uint32_t j = blockIdx.x * chains + c;
+    const bool active = lane < lanes && j < n_jobs;
+    uint8_t *mine = snk_lds8 + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * SNK_BCHAIN_B;
+
+    SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
+    if (active) job = jobs[j];
+
+    for (uint32_t l = 0; l < lanes; ++l) {
+        const int a   = __shfl((int)active, (int)l);
+        const int xi  = __shfl(job.xi, (int)l);
+        const int snp = __shfl(job.snap, (int)l);
+        if (!a) continue;
+        uint8_t *dst = snk_lds8 + (size_t)(wave * lanes + l) * SNK_BCHAIN_B;
+        const uint32_t spos = T.snap_pos[xi];
+        const bool use = (snp == 0) && (spos != 0u);
+        const uint32_t *src = T.snap_gen + (size_t)xi * 4096u;
+        for (uint32_t t = lane; t < SNK_BTBL_B / 4u; t += 64u) {
+            uint32_t v = 0u;
+            if (use && t < SNK_BSLOTS / 2u) {
+                const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
+                const uint32_t lo = (a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u;
+                const uint32_t hi = (a1 + 65536u >= spos) ? (a1 & 0xFFFFu) : 0u;
+                v = lo | (hi << 16);
+            }
+            ((uint32_t *)dst)[t] = v;
+        }
+        for (uint32_t t = lane; t < SNK_BBMWORDS; t += 64u)
+            ((uint32_t *)(dst + SNK_BTBL_B))[t] = use ? 0u : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (!active) return;
+
+    uint16_t *tbl = (uint16_t *)mine;
+    uint32_t *bm = (uint32_t *)(mine + SNK_BTBL_B);
+    SnkByteLane L;
+    const uint32_t lx = T.len[job.xi];
+    const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
+    L.s.arena = (snk_g8 *)T.bytes_arena;
+    L.s.xoff = T.bytes_off[job.xi];
+    L.s.yoff = job.yi >= 0 ? T.bytes_off[job.yi] : 16u;       // zero region at the arena start
+    L.s.lx = lx;
+    L.n = lx + ly;
+    L.spos = T.snap_pos[job.xi];
+    L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;
+    if (job.snap == 0 && L.spos != 0u) { L.pos = L.spos; L.total = T.snap_out[job.xi]; }
+    else                               { L.pos = 0u;     L.total = T.header_bytes; }
+    L.blocks_left = (L.n >> 16) + 4u;
+    L.iend = 0; L.blen = 0; L.first = true; L.in_block = false;
+    L.cur = 0; L.step = 1; L.nb = 64; L.anchor = 0; L.op = 0;
+    L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos; L.endcode = 0;
+    L.pending = false;
+    L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
+    L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.nx0 = L.w.nx1 = 0u;
+    snk_bytes_loop(L, T, tbl, bm, out, status);
 }
 
 // =========================================================================

@@ -40,7 +40,9 @@ def test_tiny_and_empty_inputs(hip, oracle_mod):
 def test_lcg_100k_fast_and_generic_paths(hip, oracle_mod):
     seqs = [oracle_mod.lcg_genome(1 + i, 100000) for i in range(6)]
     assert _check_all(hip, oracle_mod, seqs) == 6
-    _check_all(hip, oracle_mod, seqs, force_generic=1)
+    _check_all(hip, oracle_mod, seqs, force_generic=1)                      # tight-loop byte kernel
+    _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_legacy=1)      # legacy u32-table byte kernel
+    _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_lanes=4, bytes_waves=3)
 
 
 def test_ragged_lengths_around_block_edges(hip, oracle_mod):
@@ -58,6 +60,20 @@ def test_mixed_alphabets_raw_blocks_and_n_runs(hip, oracle_mod):
             np.frombuffer(lcg_bytes(31, 90000, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8),
             np.frombuffer(bytes(o.lcg_genome(25, 120000)).lower(), dtype=np.uint8)]
     assert _check_all(hip, oracle_mod, seqs) == 2
+    _check_all(hip, oracle_mod, seqs, bytes_legacy=1)
+
+
+def test_byte_kernel_on_everything(hip, oracle_mod):
+    """force_generic routes the ACGT inputs through the byte kernel too: ragged block edges,
+    long matches, low complexity, related genomes."""
+    o = oracle_mod
+    lens = [65537, 131072, 200001, 70000, 65535 + 65536, 65548, 196608]
+    seqs = [o.lcg_genome(11 + i, n) for i, n in enumerate(lens)]
+    rep = np.tile(o.lcg_genome(32, 5000), 40)
+    seqs += [np.tile(o.lcg_genome(31, 37), 3000), rep, o.lcg_mutant(rep, 5),
+             np.frombuffer(b"A" * 150000, dtype=np.uint8), np.frombuffer(b"AC" * 60000, dtype=np.uint8),
+             np.frombuffer(b"N" * 1000 + bytes(o.lcg_genome(77, 90000)) + b"n" * 3000, dtype=np.uint8)]
+    _check_all(hip, oracle_mod, seqs, force_generic=1)
 
 
 def test_long_matches_and_low_complexity(hip, oracle_mod):
@@ -173,6 +189,9 @@ def test_full_size_1mbp_properties(hip, golden, oracle_mod):
         ctx.upload(seqs)
         assert np.array_equal(ctx.singles(), s)
         assert np.array_equal(ctx.pairs(0, 3), p[:3])           # byte kernel == 2-bit kernel
+    with hip.HipContext(0, force_generic=1, bytes_legacy=1) as ctx:
+        ctx.upload(seqs[:4])
+        assert np.array_equal(ctx.pairs(0, 1), p[:1, :4])       # legacy byte kernel too
     row = golden["liblz4_frame_sizes"]["lcg_seed1_2_mut3"][2]
     assert (int(s[0]), int(s[1]), int(s[5])) == (row["x"], row["y"], row["z"])
     assert (int(p[0, 1]), int(p[1, 0]), int(p[0, 0]), int(p[0, 5]), int(p[5, 0])) == \
