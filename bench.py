@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="override fast_lanes")
     ap.add_argument("--waves", type=int, default=0, help="override fast_waves")
     ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="extra backend option key=value (repeatable)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -105,6 +106,9 @@ def main():
         opts["fast_waves"] = args.waves
     if args.force_generic:
         opts["force_generic"] = 1
+    for kv in args.opt:
+        k, v = kv.split("=")
+        opts[k] = int(v)
     ctx = HipContext(local_rank, **opts)
     t0 = time.time()
     ctx.upload(genomes)                                  # H2D + classify + pack + singles/snapshots (untimed)

@@ -42,7 +42,9 @@ enum {
     SNK_E_HIP     = -2,   /* HIP runtime error (no device, OOM, launch ...) */
     SNK_E_STATE   = -3,   /* call order (e.g. pairs before upload)          */
     SNK_E_TOOBIG  = -4,   /* a sequence or a concatenation >= 0x7E000000 B  */
-    SNK_E_KERNEL  = -5    /* device-side consistency check failed           */
+    SNK_E_KERNEL  = -5,   /* device-side consistency check failed           */
+    SNK_E_EMPTY   = -6,   /* FASTA ingest: no sequence in the file (Python: ValueError)        */
+    SNK_E_MIXED   = -7    /* FASTA ingest: T and U in one record under reverse complement      */
 };
 
 typedef struct snk_ctx snk_ctx;
@@ -105,6 +107,22 @@ int snk_sync(snk_ctx *ctx, void *hip_stream);
  * last snk_pairs / snk_pairs_device / snk_pairs_list call; for
  * snk_pairs_device it is valid after snk_sync().  Returns < 0 if unavailable. */
 double snk_last_pairs_ms(snk_ctx *ctx);
+
+/* ---- FASTA ingest on the host ------------------------------------------
+ * Replaces extract_sequences (ref:snacc/pairwise_ncd.py:15-39: Bio.SeqIO.parse + per-record
+ * reverse_complement + concatenation) for the batched path: every file is parsed once, by
+ * n_threads host threads, without creating Python strings.  Results are malloc'ed byte strings
+ * (free with snk_free).  Errors: SNK_E_ARG (I/O), SNK_E_EMPTY (the reference's "No sequence
+ * extracted" ValueError), SNK_E_MIXED (Biopython's "Mixed RNA/DNA found"); message via
+ * snk_fasta_last_error() (thread-local). */
+int snk_fasta_extract(const char *path, int reverse_complement, uint8_t **out, uint64_t *out_len);
+int snk_fasta_extract_many(int n, const char *const *paths, int reverse_complement, int n_threads,
+                           uint8_t **outs /* [n] */, uint64_t *lens /* [n] */);
+const char *snk_fasta_last_error(void);
+void snk_free(void *p);
+
+/* Ingest + snk_upload in one call: the sequence bytes never enter the caller's language runtime. */
+int snk_upload_fasta(snk_ctx *ctx, int n, const char *const *paths, int reverse_complement, int n_threads);
 
 #ifdef __cplusplus
 }

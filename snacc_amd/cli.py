@@ -49,7 +49,24 @@ def discover_files(sequences, fasta=(), directories=()):
 def write_matrix_csv(files, matrix, output):
     """CSV exactly as ``DataFrame.pivot(index='file', columns='file2', values='ncd').to_csv``
     writes it (ref:snacc/cli.py:138-142): header ``file,<path>...``, one row per file, rows and
-    columns in the sort order pandas gives ``Path`` objects."""
+    columns in the sort order pandas gives ``Path`` objects, floats in shortest round-trip form,
+    minimal quoting, ``os.linesep`` line ends.  Written directly: building the
+    reference's 1 M-row long-form DataFrame and pivoting it is the slow part at N >= 1024;
+    ``tests/test_host_logic.py`` checks byte equality with the pandas route."""
+    import csv
+    order = sorted(range(len(files)), key=lambda i: files[i])
+    labels = [str(files[i]) for i in order]
+    m = np.asarray(matrix, dtype=np.float64)[np.ix_(order, order)]
+    with open(output, "w", newline="") as f:
+        wr = csv.writer(f, lineterminator=os.linesep, quoting=csv.QUOTE_MINIMAL)
+        wr.writerow(["file"] + labels)
+        for label, row in zip(labels, m.tolist()):
+            wr.writerow([label] + ["" if v != v else repr(v) for v in row])
+
+
+def write_matrix_csv_pandas(files, matrix, output):
+    """The pandas route (what the reference does after its pivot); kept as the checker for
+    :func:`write_matrix_csv`."""
     order = sorted(range(len(files)), key=lambda i: files[i])
     labels = [files[i] for i in order]
     m = np.asarray(matrix)[np.ix_(order, order)]
@@ -71,12 +88,12 @@ def lz4_matrix(files, reverse_complement, show_progress):
 
     world, rank = _dist_env()
     click.secho("Compressing individual files...", fg="green")
-    it = tqdm(files) if (show_progress and rank == 0) else files
-    seqs = [bytes(extract_sequences(f, reverse_complement=reverse_complement), encoding="utf-8") for f in it]
-    n = len(seqs)
+    n = len(files)
     ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")))
     try:
-        ctx.upload(seqs)
+        # every file is parsed ONCE, by host threads inside the library, then
+        # uploaded; phase A (singles + prefix snapshots) runs as part of the upload
+        ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
         singles = ctx.singles().astype(np.int64) + GETSIZEOF_OVERHEAD
         click.secho("Compressing pairs...", fg="green")
         if world > 1:

@@ -21,6 +21,7 @@ EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
     "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_sync", "snk_last_pairs_ms",
+    "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
 )
 
 
@@ -34,7 +35,7 @@ _lib = None
 def build(force=False):
     """Compile the library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("snacc_hip.hip", "snk_device.hip.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("snacc_hip.hip", "snk_device.hip.h", "snk_fasta.cpp")]
     srcs.append(os.path.join(_HERE, "..", "include", "snacc_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -94,6 +95,16 @@ def load():
     L.snk_sync.argtypes = [vp, vp]
     L.snk_last_pairs_ms.restype = ctypes.c_double
     L.snk_last_pairs_ms.argtypes = [vp]
+    L.snk_fasta_extract.restype = i32
+    L.snk_fasta_extract.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    L.snk_fasta_extract_many.restype = i32
+    L.snk_fasta_extract_many.argtypes = [i32, vp, i32, i32, vp, vp]
+    L.snk_fasta_last_error.restype = ctypes.c_char_p
+    L.snk_fasta_last_error.argtypes = []
+    L.snk_free.restype = None
+    L.snk_free.argtypes = [vp]
+    L.snk_upload_fasta.restype = i32
+    L.snk_upload_fasta.argtypes = [vp, i32, vp, i32, i32]
     if L.snk_version() != ABI_VERSION:
         raise HipBackendError(f"ABI mismatch: library {L.snk_version()}, binding {ABI_VERSION}")
     _lib = L
@@ -106,6 +117,36 @@ def _as_u8(seq):
     if isinstance(seq, str):
         seq = seq.encode("utf-8")  # ref:snacc/pairwise_ncd.py:69  bytes(sequence, encoding="utf-8")
     return np.frombuffer(seq, dtype=np.uint8)
+
+
+E_EMPTY, E_MIXED = -6, -7
+
+
+def _raise_fasta(L, rc):
+    msg = L.snk_fasta_last_error().decode(errors="replace")
+    if rc in (E_EMPTY, E_MIXED):
+        raise ValueError(msg)              # the reference's / Biopython's exception type
+    raise HipBackendError(f"FASTA ingest failed [{rc}]: {msg}")
+
+
+def fasta_extract(path, reverse_complement=False):
+    """Native ``extract_sequences`` for one file -> ``bytes`` (host only, no GPU needed)."""
+    L = load()
+    out, n = ctypes.c_void_p(), ctypes.c_uint64()
+    rc = L.snk_fasta_extract(os.fsencode(str(path)), int(bool(reverse_complement)), ctypes.byref(out), ctypes.byref(n))
+    if rc != 0:
+        _raise_fasta(L, rc)
+    try:
+        return ctypes.string_at(out, n.value)
+    finally:
+        L.snk_free(out)
+
+
+def default_threads():
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 32))
+    except AttributeError:
+        return max(1, min(os.cpu_count() or 1, 32))
 
 
 class HipContext:
@@ -157,6 +198,18 @@ class HipContext:
         ptrs = (ctypes.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
         lens = (ctypes.c_uint64 * max(n, 1))(*[a.size for a in arrs])
         self._check(self._L.snk_upload(self._h, n, ptrs, lens), "snk_upload")
+        self.n = n
+        return self
+
+    def upload_fasta(self, paths, reverse_complement=False, threads=None):
+        """Parse every FASTA file once on host threads (C++) and upload; the sequence bytes never
+        become Python objects.  Raises ValueError like the reference for empty/malformed files."""
+        paths = [os.fsencode(str(p)) for p in paths]
+        n = len(paths)
+        arr = (ctypes.c_char_p * max(n, 1))(*paths)
+        rc = self._L.snk_upload_fasta(self._h, n, arr, int(bool(reverse_complement)), threads or default_threads())
+        if rc != 0:
+            _raise_fasta(self._L, rc)
         self.n = n
         return self
 

@@ -10,7 +10,7 @@ import pytest
 from conftest import materialise_cli_set
 from snacc_amd import compressed_size, compute_distance
 from snacc_amd import fasta
-from snacc_amd.cli import discover_files, write_matrix_csv
+from snacc_amd.cli import discover_files, write_matrix_csv, write_matrix_csv_pandas
 from snacc_amd.matrix import GETSIZEOF_OVERHEAD, ncd_matrix
 from snacc_amd.pairwise_ncd import extract_sequences
 
@@ -129,3 +129,19 @@ def test_discover_files_rules(tmp_path):
     extra.write_text(">x\nACGT\n")
     files = discover_files([str(d), str(extra), str(d / "a.fa")])
     assert [f.name for f in files] == ["a.fa", "b.FASTA", "d.faa", "z.txt"]     # non-recursive, dedup, sorted
+
+
+def test_direct_csv_writer_equals_pandas(tmp_path):
+    """the direct writer must produce the bytes pandas' to_csv produces."""
+    rng = np.random.default_rng(5)
+    n = 40
+    m = rng.random((n, n)) * 1.2
+    m[0, 1] = 1.0; m[1, 0] = 1e-7; m[2, 2] = 123456789.125; m[3, 4] = 0.1 + 0.2; m[5, 5] = 1e22; m[6, 7] = 5e-324
+    files = [Path(f"/data/set, one/g{i:03d}.fa") if i % 9 == 0 else Path(f"/data/x/g{i:03d}.fasta") for i in range(n)]
+    files[3] = Path('/data/we"ird/q.fa')
+    files[11] = Path("/data/x/a.b")           # Path order != string order against /data/x/a/...
+    files[12] = Path("/data/x/a/b")
+    a, b = tmp_path / "direct.csv", tmp_path / "pandas.csv"
+    write_matrix_csv(files, m, a)
+    write_matrix_csv_pandas(files, m, b)
+    assert a.read_bytes() == b.read_bytes()
