@@ -141,6 +141,12 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", chains);
         HIPCHK(c, hipFuncSetAttribute((const void *)snk_fast_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {   // the kernel addresses its slot LUT at LDS offset 0: that holds only without static LDS
+            hipFuncAttributes fa;
+            HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)snk_fast_kernel));
+            if (fa.sharedSizeBytes != 0)
+                return fail(c, SNK_E_STATE, "snk_fast_kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+        }
         const uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
         hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st,
                            T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);

@@ -403,6 +403,10 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
     SnkWin &w = L.w;
     snk_g8 *const arena = L.s.arena;
     const uint32_t ybias = L.s.lx + 4u;          // candidate window of stream position p starts at y base p - ybias
+    // The slot LUT sits at LDS address 0 (the kernel has no static LDS; the host checks it):
+    // indexing it from a constant base saves the per-read base addition.
+    (void)slot;
+    const __attribute__((address_space(3))) uint16_t *const lut0 = (const __attribute__((address_space(3))) uint16_t *)0;
 
     for (;;) {
         // ======== head: serve rare pre-conditions, then start the LUT reads ========
@@ -428,33 +432,36 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             if (!YONLY && __all(L.yflag)) return SNK_LOOP_SWITCH;
         }
         uint32_t wc = __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
-        uint32_t s1 = slot[(wc >> 8) & 1023u];
-        uint32_t s2 = slot[(wc >> 4) & 1023u];
+        uint32_t s1 = lut0[(wc >> 8) & 1023u];
+        uint32_t s2e = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);   // nothing owed: unused slot
+        uint32_t nxoff = w.soff + ((w.rb + 32u - w.org) >> 2);      // arena offset of the bases [rb+32, rb+48)
+        const uint32_t olim6 = L.olimit - 6u;                       // olimit >= 12 inside an open block
 
         // ======== steady state: one probe per trip, LUT reads for the next one already in flight ========
         for (;;) {
-            s2 = L.pending ? s2 : (SNK_FSLOTS - 1u);
-            const uint32_t e = tbl[s1];
-            const uint32_t bw = bm[s1 >> 5];
             const uint32_t c = cur - L.base;
             const uint32_t bit1 = 1u << (s1 & 31u);
-            tbl[s2] = (uint16_t)(c - 2u);
-            atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+            // liblz4's order: put(cur-2), then read the slot of cur, then put(cur).  The LDS executes a
+            // wave's operations in issue order, so a put to the same slot is seen by the read.
+            // Only the cheap 16-bit write of the owed put goes in front of the read; its bitmap bit
+            // follows the read and is patched in by one compare.
+            tbl[s2e] = (uint16_t)(c - 2u);
+            const uint32_t e = tbl[s1];
+            const uint32_t bw = bm[s1 >> 5];
+            atomicOr(&bm[s2e >> 5], 1u << (s2e & 31u));
             tbl[s1] = (uint16_t)c;
             atomicOr(&bm[s1 >> 5], bit1);
-            const bool iscur = (bw & bit1) != 0u;
-            uint32_t cand = L.base + e - (iscur ? 0u : 65536u);
-            bool valid = iscur | (e > c);
-            const bool same = (s2 == s1);
-            cand = same ? cur - 2u : cand;
-            valid |= same;
+            const bool hit = (bw & bit1) != 0u;
+            const bool same = (s2e == s1);
+            const bool iscur = hit || same;
+            const bool valid = iscur || (e > c);
+            uint32_t cand = (iscur ? L.base : L.base - 65536u) + e;
             cand = valid ? cand : cur;
 
             __builtin_amdgcn_sched_barrier(0);
-            snk_g8 *nxp = arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2));
             const uint32_t wd = YONLY ? snk_w32_at(arena, L.s.yoff, (int32_t)(cand - ybias))
                                       : snk_fetch32_nobranch(L.s, cand);
-            w.nx = snk_ld4g(nxp);
+            w.nx = snk_ld4g(arena + (size_t)nxoff);
             __builtin_amdgcn_sched_barrier(0);
 
             const uint32_t x = wc ^ wd;
@@ -470,12 +477,14 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             const uint32_t nnext = ncur + nstep;
             uint32_t no = ncur - 4u - w.rb;
             const bool sl = (no - 16u) < 16u;
+            const uint32_t sl16 = sl ? 16u : 0u;
             const uint32_t r0n = sl ? w.r1 : w.r0;       // w.nx (just refilled, waited for with wd)
             const uint32_t r1n = sl ? w.nx : w.r1;
-            no -= sl ? 16u : 0u;
+            no -= sl16;
             const uint32_t nwc = __builtin_amdgcn_alignbit(r1n, r0n, 2u * (no & 15u));
-            const uint32_t ns1 = slot[(nwc >> 8) & 1023u];
-            const uint32_t ns2 = slot[(nwc >> 4) & 1023u];
+            const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
+            const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
+            __builtin_amdgcn_sched_barrier(0);           // keep the LUT reads in front of the bookkeeping
 
             // ---- bookkeeping of this probe, in the shadow of the LUT reads ----
             const uint32_t anchor0 = L.anchor, op0 = L.op;
@@ -486,25 +495,26 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             lit -= b;
             const uint32_t mc = e2 - (cur - b) - 4u;
             const uint32_t opn = op0 + lit + 3u;
-            const uint32_t big = lit > mc ? lit : mc;
-            // (a match that ends the block needs no special case: the head closes the block from
-            //  the committed op/anchor exactly as liblz4's last-literals does)
-            const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit));
+            // rare: back-extension reaches 4 (b+11 >= 15), match reaches 12 (f+3 >= 15), a length needs
+            // extension bytes (>= 15), or the output budget is at risk.  (A match that ends the block
+            // needs no special case: the head closes the block from the committed op/anchor.)
+            uint32_t mx = lit > mc ? lit : mc;
+            { const uint32_t t1 = b + 11u, t2 = f + 3u; const uint32_t t3 = t1 > t2 ? t1 : t2; mx = mx > t3 ? mx : t3; }
+            const bool rare = m & ((mx >= 15u) | (opn > olim6));
+            const bool pre = (nnext > L.mfl1) | (no > 15u) | (!YONLY && ncur > w.lim);
             L.op = m ? opn : op0;
             L.anchor = m ? e2 : anchor0;
-            L.cur = ncur;
             L.step = nstep;
             L.nb = m ? 63u : L.nb + 1u;
-            L.pending = m;
-            w.r0 = r0n; w.r1 = r1n; w.rb += sl ? 16u : 0u;
-            const bool pre = (nnext > L.mfl1) | (no > 15u) | (!YONLY && ncur > w.lim);
-            if (__builtin_expect(__any(rare | pre), 0)) {
+            w.r0 = r0n; w.r1 = r1n; w.rb += sl16; nxoff += sl16 >> 2;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare | pre) != 0ull, 0)) {
+                L.cur = ncur; L.pending = m;
                 if (rare) snk_fast_match_slow(L, cur, cand, f, anchor0, op0);
                 // restore the head invariant: the reservoir may just have slid
-                w.nx = snk_ld4g(arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2)));
+                w.nx = snk_ld4g(arena + (size_t)nxoff);
                 break;                                   // the head re-derives everything from L
             }
-            cur = ncur; next = nnext; wc = nwc; s1 = ns1; s2 = ns2;
+            cur = ncur; next = nnext; wc = nwc; s1 = ns1; s2e = m ? ns2 : (SNK_FSLOTS - 1u);
         }
     }
 }
