@@ -548,6 +548,14 @@ int snk_pairs_list(snk_ctx *c, int n_pairs, const int32_t *ij, uint32_t *sizes)
     return SNK_OK;
 }
 
+#ifdef SNK_STAMP
+/* diagnostic build only (not part of the shipped ABI) */
+int snk_debug_read_stamps(unsigned long long *out8)
+{
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(snk_stamp_buf), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 double snk_last_pairs_ms(snk_ctx *c)
 {
     if (!c || !c->ev_valid) return -1.0;

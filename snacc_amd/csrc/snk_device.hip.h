@@ -383,6 +383,12 @@ __device__ __forceinline__ uint32_t snk_fetch32_nobranch(const SnkFastSrc &s, ui
     return iny ? yv : (inx ? xv : mix);
 }
 
+#ifdef SNK_STAMP
+__device__ unsigned long long snk_stamp_buf[8];     // diagnostic build only; read by snk_debug_read_stamps
+#define SNK_STAMP_T(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SNK_STAMP_T(v) do { } while (0)
+#endif
 #define SNK_LOOP_DONE   0
 #define SNK_LOOP_SWITCH 1
 
@@ -406,6 +412,10 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
     // The slot LUT sits at LDS address 0 (the kernel has no static LDS; the host checks it):
     // indexing it from a constant base saves the per-read base addition.
     (void)slot;
+#ifdef SNK_STAMP
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    unsigned long long acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, iters = 0;
+#endif
     const __attribute__((address_space(3))) uint16_t *const lut0 = (const __attribute__((address_space(3))) uint16_t *)0;
 
     for (;;) {
@@ -439,6 +449,7 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
 
         // ======== steady state: one probe per trip, LUT reads for the next one already in flight ========
         for (;;) {
+            SNK_STAMP_T(t0);
             const uint32_t c = cur - L.base;
             const uint32_t bit1 = 1u << (s1 & 31u);
             // liblz4's order: put(cur-2), then read the slot of cur, then put(cur).  The LDS executes a
@@ -457,7 +468,10 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             const bool valid = iscur || (e > c);
             uint32_t cand = (iscur ? L.base : L.base - 65536u) + e;
             cand = valid ? cand : cur;
-
+#ifdef SNK_STAMP
+            asm volatile("" :: "v"(cand));
+            SNK_STAMP_T(t1);                                  // table data arrived, candidate known
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t wd = YONLY ? snk_w32_at(arena, L.s.yoff, (int32_t)(cand - ybias))
                                       : snk_fetch32_nobranch(L.s, cand);
@@ -465,6 +479,11 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             __builtin_amdgcn_sched_barrier(0);
 
             const uint32_t x = wc ^ wd;
+#ifdef SNK_STAMP
+            asm volatile("" :: "v"(x));
+            __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0)
+            SNK_STAMP_T(t2);                                  // candidate window arrived
+#endif
             const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;
             const bool m = valid & (f >= 4u);
             uint32_t e2 = cur + f;
@@ -485,6 +504,9 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
             const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
             __builtin_amdgcn_sched_barrier(0);           // keep the LUT reads in front of the bookkeeping
+#ifdef SNK_STAMP
+            SNK_STAMP_T(t3);                                  // next LUT reads issued
+#endif
 
             // ---- bookkeeping of this probe, in the shadow of the LUT reads ----
             const uint32_t anchor0 = L.anchor, op0 = L.op;
@@ -515,6 +537,14 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
                 break;                                   // the head re-derives everything from L
             }
             cur = ncur; next = nnext; wc = nwc; s1 = ns1; s2e = m ? ns2 : (SNK_FSLOTS - 1u);
+#ifdef SNK_STAMP
+            asm volatile("" :: "v"(s1), "v"(s2e));            // forces the LUT data to have arrived
+            SNK_STAMP_T(t4);
+            acc1 += t1 - t0; acc2 += t2 - t1; acc3 += t3 - t2; acc4 += t4 - t3; iters++;
+            if (YONLY && blockIdx.x == 0 && threadIdx.x == 0 && (iters & 1023) == 0) {
+                snk_stamp_buf[0] = acc1; snk_stamp_buf[1] = acc2; snk_stamp_buf[2] = acc3; snk_stamp_buf[3] = acc4; snk_stamp_buf[4] = iters;
+            }
+#endif
         }
     }
 }
