@@ -85,11 +85,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # SNACC_BENCH_REHEARSE=1: exercise the multi-rank code path on ONE GPU (all ranks on device 0,
+    # gloo with host staging for the gather).  Never used for reported numbers.
+    rehearse = os.environ.get("SNACC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from snacc_amd.hip_backend import HipContext
 
@@ -126,11 +134,21 @@ def main():
     tile = torch.zeros((R, N), dtype=torch.int32, device=dev)     # u32 sizes, viewed as int32
     gathered = torch.zeros((world * R, N), dtype=torch.int32, device=dev) if world > 1 else None
 
+    def gather():
+        if world == 1:
+            return
+        if rehearse:                                   # gloo: stage through the host
+            stream.synchronize()
+            parts = [torch.zeros((R, N), dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(parts, tile.cpu())
+            gathered.copy_(torch.cat(parts).to(dev))
+        else:
+            dist.all_gather_into_tensor(gathered, tile)
+
     def step(k):
         r0 = shard0 + (k * R) % max(rows_per_rank - R + 1, 1)
         ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, tile)
+        gather()
         return r0
 
     def fence():
@@ -154,8 +172,7 @@ def main():
     for k in range(args.steps):
         r0 = shard0 + ((args.warmup + k) * R) % max(rows_per_rank - R + 1, 1)
         ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, tile)
+        gather()
         last_r0 = r0
     ev_end.record(stream)
     fence()
@@ -164,7 +181,7 @@ def main():
     lib_last_ms = ctx.last_pairs_ms()                     # the library's own event pair, last launch
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     # Launch duration of the dominant kernel: the library brackets every launch with its own
@@ -179,6 +196,13 @@ def main():
     ncd_rate = pair_rate / 2.0                            # 1 NCD = 2 ordered pair-compressions
     alg_bytes_launch = R * N * (2 * L + 4)                # per launch (one rank): len_i + len_j read + 4 B written
     achieved = alg_bytes_launch / (kern_ms_avg * 1e-3) / 1e9
+
+    gather_ok = None
+    if world > 1:                                       # every rank's tile must be in its slot of the gather
+        gather_ok = bool(torch.equal(gathered[rank * R:(rank + 1) * R], tile))
+        flag = torch.tensor([1 if gather_ok else 0], dtype=torch.int32, device="cpu" if rehearse else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_ok = bool(flag.item())
 
     # spot parity of the last tile against the oracle (checker only; not in the timed region)
     parity = None
@@ -225,7 +249,7 @@ def main():
                          "kernel_ms_avg": kern_ms_avg, "kernel_ms_region_torch_events": kern_ms_region,
                          "alg_bytes_per_launch": alg_bytes_launch},
             "cpu_baseline": cpu_baseline,
-            "parity_spot_check": parity,
+            "parity_spot_check": parity, "allgather_check": gather_ok,
             "setup_s": {"generate": round(t_gen, 2), "upload_and_singles": round(t_upload, 2)},
         }
         print(json.dumps(line), flush=True)

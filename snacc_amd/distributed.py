@@ -58,10 +58,12 @@ def all_pairs_hip(ctx, n, group=None):
     def rows_fn(r0, r1):
         out = torch.zeros((max(r1 - r0, 0), n), dtype=torch.int32, device=dev)
         torch.cuda.current_stream(dev).synchronize()      # the fill must land before another stream writes
-        if r1 > r0:
-            # launch on the context's own stream (NULL) and wait for it: the tile is complete
-            # before the collective is enqueued on torch's stream
-            ctx.pairs_device(r0, r1, out.data_ptr(), None)
+        # launch on the context's own stream (NULL), in row tiles of bounded job-list size, and wait:
+        # the shard is complete before the collective is enqueued on torch's stream
+        tile = max(1, min(r1 - r0, (4 << 20) // max(n, 1)))
+        for t0 in range(r0, r1, tile):
+            t1 = min(r1, t0 + tile)
+            ctx.pairs_device(t0, t1, out.data_ptr() + (t0 - r0) * n * 4, None)
             ctx.sync(None)
         return out
 
