@@ -244,3 +244,48 @@ def test_config3_sample_1024x1mbp(hip, oracle_mod):
     from snacc_amd.matrix import ncd_matrix
     m = ncd_matrix(s.astype(np.int64) + 33, p.astype(np.int64) + 33)
     assert np.array_equal(m, m.T) and m[0, 1] == 0.999350356687629
+
+
+def test_config5_substitute_5mbp_reverse_complement_cli(hip, oracle_mod, tmp_path, monkeypatch):
+    """BASELINE.json configs[4] names 92 E. coli genomes that are not in the reference (SURVEY.md 8d);
+    substitute: 10 synthetic ~5 Mbp multi-record genomes (2 % mutants of two ancestors), `-c lz4 -r`
+    through the CLI, every matrix cell compared with the oracle-derived NCD."""
+    from click.testing import CliRunner
+    from conftest import write_fasta
+    from oracle.loader import pairs_mt
+    from snacc_amd import fasta
+    from snacc_amd.cli import cli
+    from snacc_amd.matrix import ncd_matrix
+    o = oracle_mod
+    anc = [o.lcg_genome(900 + a, 5_000_000 + 12345 * a) for a in range(2)]
+    d = tmp_path / "fa"
+    d.mkdir()
+    seqs_rc = []
+    for i in range(10):
+        g = bytes(anc[i % 2] if i < 2 else o.lcg_mutant(anc[i % 2], 1000 + i)).decode()
+        cut = [0, len(g) // 3 + 17 * i, 2 * len(g) // 3, len(g)]                 # three records per file
+        recs = [(f"g{i}_c{k}", g[cut[k]:cut[k + 1]]) for k in range(3)]
+        write_fasta(d / f"g{i:02d}.fna", recs, width=70)
+        seqs_rc.append("".join(fasta.reverse_complement(r) for _, r in recs).encode())
+    out = tmp_path / "out.csv"
+    monkeypatch.chdir(tmp_path)
+    res = CliRunner().invoke(cli, [str(d), "-o", str(out), "-c", "lz4", "-r", "--no-show-progress", "--no-log"])
+    assert res.exit_code == 0, res.output
+    got = np.loadtxt(out, delimiter=",", skiprows=1, usecols=range(1, 11))
+    singles = np.array([o.lz4f_size(s_) for s_ in seqs_rc], dtype=np.int64) + 33
+    pairs = pairs_mt([np.frombuffer(s_, dtype=np.uint8) for s_ in seqs_rc], 0, 10, _threads()).astype(np.int64) + 33
+    want = ncd_matrix(singles, pairs)
+    assert np.array_equal(got, want)                # repr round-trips: exact, well inside the 1e-6 of north_star
+
+
+def test_edge_cases_single_sequence_and_duplicates(hip, oracle_mod):
+    o = oracle_mod
+    g = o.lcg_genome(5, 150000)
+    with hip.HipContext(0) as ctx:
+        ctx.upload([g])
+        assert ctx.pairs().tolist() == [[o.lz4f_size_pair(g, g)]]
+        ctx.upload([g, g.copy(), g.copy()])
+        p = ctx.pairs()
+        assert (p == p[0, 0]).all() and int(p[0, 0]) == o.lz4f_size_pair(g, g)
+        ctx.upload([])
+        assert ctx.singles().size == 0 and ctx.pairs().size == 0
