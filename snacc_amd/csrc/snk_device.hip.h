@@ -859,35 +859,44 @@ __device__ __forceinline__ uint32_t snk_bbyte(const SnkByteSrc &s, uint32_t p)
     return p < s.lx ? s.arena[(size_t)(s.xoff + p)] : s.arena[(size_t)(s.yoff + (p - s.lx))];
 }
 
-// Candidate window for the tight loop: bytes [p-1, p+7), branch-free (x and y windows always in
-// flight together; a straddling window is x's zero-padded tail OR y's head shifted into place).
-__device__ __forceinline__ uint64_t snk_bfetch8_nobranch(const SnkByteSrc &s, uint32_t p)
+struct __attribute__((packed)) SnkU96 { uint32_t a, b, c; };
+struct SnkW12 { uint32_t a, b, c; };               // 12 bytes [p-4, p+8): a = p-4..p-1, b = p..p+3, c = p+4..p+7
+
+// Candidate window for the tight loop: the 12 bytes [p-4, p+8) of the concatenation.  The source
+// (x or y) is chosen by select; a window that straddles the seam is assembled by the slow loader
+// (wave-uniform branch, taken only within 12 bytes of the seam).
+__device__ __forceinline__ SnkW12 snk_bfetch12(const SnkByteSrc &s, uint32_t p)
 {
-    const int32_t q0 = (int32_t)p - 1;
-    const bool inx = (p + 7u <= s.lx);
+    const int32_t q0 = (int32_t)p - 4;
     const bool iny = (q0 >= (int32_t)s.lx);
-    const uint64_t xv = snk_ld8g(s.arena + (size_t)(uint32_t)((int32_t)s.xoff + (iny ? 0 : q0)));
-    const uint64_t yv = snk_ld8g(s.arena + (size_t)(s.yoff + (iny ? (uint32_t)(q0 - (int32_t)s.lx) : 0u)));
-    const uint32_t k = (uint32_t)((int32_t)s.lx - q0) & 7u;   // 1..7 when straddling
-    const uint64_t mix = xv | (yv << (8u * k));
-    return iny ? yv : (inx ? xv : mix);
+    const bool straddle = !iny & (p + 8u > s.lx);
+    const uint32_t off = iny ? s.yoff + (uint32_t)(q0 - (int32_t)s.lx) : (uint32_t)((int32_t)s.xoff + q0);
+    const __attribute__((address_space(1))) SnkU96 *vp = (const __attribute__((address_space(1))) SnkU96 *)(s.arena + (size_t)off);
+    SnkW12 r; r.a = vp->a; r.b = vp->b; r.c = vp->c;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(straddle) != 0ull, 0)) {
+        if (straddle) {
+            const uint64_t lo = snk_bld8(s, (uint32_t)q0), hi = snk_bld8(s, (uint32_t)q0 + 8u);
+            r.a = (uint32_t)lo; r.b = (uint32_t)(lo >> 32); r.c = (uint32_t)hi;
+        }
+    }
+    return r;
 }
 
-// Cursor-side reservoir: 20 bytes [rb, rb+20) of ONE source in registers plus the next 8 in
-// flight.  A probe at cur needs bytes [cur-2, cur+10): offset o = cur-2-rb must be 0..7.
+// Cursor-side reservoir: 24 bytes [rb, rb+24) of ONE source in registers plus the next 8 in
+// flight.  A probe at cur needs the bytes [cur-4, cur+8): offset o = cur-4-rb must be 0..7.
 struct SnkBWin {
     uint32_t soff, org, rb, lim;       // lim = largest cursor this source can serve (0 = unusable)
-    uint32_t r0, r1, r2, r3, r4, nx0, nx1;
+    uint32_t r0, r1, r2, r3, r4, r5, nx0, nx1;
 };
 
 __device__ __forceinline__ void snk_bwin_init(SnkBWin &w, snk_g8 *arena, uint32_t soff, uint32_t org,
                                               uint32_t lim, uint32_t cur)
 {
     w.soff = soff; w.org = org; w.lim = lim;
-    w.rb = org + ((cur - 2u - org) & ~3u);
+    w.rb = org + ((cur - 4u - org) & ~3u);
     snk_g8 *p = arena + (size_t)(soff + (w.rb - org));
     w.r0 = snk_ld4g(p); w.r1 = snk_ld4g(p + 4); w.r2 = snk_ld4g(p + 8); w.r3 = snk_ld4g(p + 12);
-    w.r4 = snk_ld4g(p + 16); w.nx0 = snk_ld4g(p + 20); w.nx1 = snk_ld4g(p + 24);
+    w.r4 = snk_ld4g(p + 16); w.r5 = snk_ld4g(p + 20); w.nx0 = snk_ld4g(p + 24); w.nx1 = snk_ld4g(p + 28);
 }
 
 struct SnkByteLane {
@@ -904,23 +913,22 @@ struct SnkByteLane {
     SnkBWin w;
 };
 
-// Data of one probe taken from the reservoir at byte offset o (0..7): the compare window
-// [cur-1, cur+7) and the two table slots (5-mers at cur and at cur-2).
-struct SnkBProbeData { uint32_t wlo, whi, s1, s2; };
+// Data of one probe taken from the reservoir at byte offset o (0..7): the 12-byte compare window
+// and the two table slots (5 bytes at cur and at cur-2).
+struct SnkBProbeData { SnkW12 w; uint32_t s1, s2; };
 
 __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t o)
 {
     const bool hi = (o & 4u) != 0u;
     const uint32_t sh = (o & 3u) * 8u;
     const uint32_t a0 = hi ? w.r1 : w.r0, a1 = hi ? w.r2 : w.r1, a2 = hi ? w.r3 : w.r2, a3 = hi ? w.r4 : w.r3;
-    const uint32_t e0 = __builtin_amdgcn_alignbit(a1, a0, sh);       // bytes cur-2 .. cur+1
-    const uint32_t e1 = __builtin_amdgcn_alignbit(a2, a1, sh);       // bytes cur+2 .. cur+5
-    const uint32_t e2 = __builtin_amdgcn_alignbit(a3, a2, sh);       // bytes cur+6 .. cur+9
     SnkBProbeData d;
-    d.wlo = __builtin_amdgcn_alignbit(e1, e0, 8);                    // bytes cur-1 .. cur+2
-    d.whi = __builtin_amdgcn_alignbit(e2, e1, 8);                    // bytes cur+3 .. cur+6
-    d.s2 = snk_hash5_parts(e0 << 24, __builtin_amdgcn_alignbit(e1, e0, 8));               // 5 bytes at cur-2
-    d.s1 = snk_hash5_parts((e0 << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(e1, e0, 24)); // 5 bytes at cur
+    d.w.a = __builtin_amdgcn_alignbit(a1, a0, sh);       // bytes cur-4 .. cur-1
+    d.w.b = __builtin_amdgcn_alignbit(a2, a1, sh);       // bytes cur   .. cur+3
+    d.w.c = __builtin_amdgcn_alignbit(a3, a2, sh);       // bytes cur+4 .. cur+7
+    // 5 bytes at cur-2 = window bytes 2..6 ; 5 bytes at cur = window bytes 4..8
+    d.s2 = snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24));
+    d.s1 = snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8));
     return d;
 }
 
@@ -1050,13 +1058,13 @@ __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTab
     }
     // seat the reservoir for the tight loop when the new cursor allows it
     const uint32_t nc = L.cur;
-    if (nc >= L.s.lx + 2u)                         snk_bwin_init(L.w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, nc);
-    else if (nc >= 2u && nc + 10u <= L.s.lx)       snk_bwin_init(L.w, L.s.arena, L.s.xoff, 0u, L.s.lx - 10u, nc);
+    if (nc >= L.s.lx + 4u)                         snk_bwin_init(L.w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, nc);
+    else if (nc >= 4u && nc + 8u <= L.s.lx)        snk_bwin_init(L.w, L.s.arena, L.s.xoff, 0u, L.s.lx - 8u, nc);
     else                                           L.w.lim = 0u;
     return false;
 }
 
-// Tight loop.  Invariant at the head: (nx0, nx1) hold the bytes [rb+20, rb+28).
+// Tight loop.  Invariant at the head: (nx0, nx1) hold the bytes [rb+24, rb+32).
 __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                uint32_t *out, uint32_t *status)
 {
@@ -1067,30 +1075,32 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
         for (;;) {
             cur = L.cur;
             next = cur + L.step;
-            o = cur - 2u - w.rb;
+            o = cur - 4u - w.rb;
             const bool pre = (next > L.mfl1) | (o > 7u) | (cur > w.lim);
-            if (__builtin_expect(!__any(pre), 1)) break;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
             if (pre && snk_bytes_iter_slow(L, T, tbl, bm, out, status)) return;
         }
         SnkBProbeData d = snk_bextract(w, o);
+        const uint32_t olim6 = L.olimit - 6u;
 
         for (;;) {
             uint32_t cand; bool valid;
             snk_bytes_table(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
 
             __builtin_amdgcn_sched_barrier(0);
-            snk_g8 *nxp = arena + (size_t)(w.soff + (w.rb + 20u - w.org));
-            const uint64_t wd = snk_bfetch8_nobranch(L.s, cand);
+            snk_g8 *nxp = arena + (size_t)(w.soff + (w.rb + 24u - w.org));
+            const SnkW12 wd = snk_bfetch12(L.s, cand);
             const uint64_t nxv = snk_ld8g(nxp);
             __builtin_amdgcn_sched_barrier(0);
             w.nx0 = (uint32_t)nxv; w.nx1 = (uint32_t)(nxv >> 32);
 
-            const uint32_t xlo = d.wlo ^ (uint32_t)wd, xhi = d.whi ^ (uint32_t)(wd >> 32);
-            // forward equal bytes from cur: bytes 1..7 of the windows
-            const uint32_t f_lo = __builtin_amdgcn_alignbit(xhi, xlo, 8);          // diff of bytes cur .. cur+3
-            const uint32_t f_hi = (xhi >> 8) | 0x01000000u;                         // diff of bytes cur+4 .. cur+6, sentinel
-            const uint32_t f = f_lo ? ((uint32_t)__builtin_ctz(f_lo) >> 3) : 4u + ((uint32_t)__builtin_ctz(f_hi) >> 3);
-            const bool m = valid & (f_lo == 0u);
+            const uint32_t x0 = d.w.a ^ wd.a, x1 = d.w.b ^ wd.b, x2 = d.w.c ^ wd.c;
+            // equal bytes forward from cur (0..8) and backward before cur (0..4)
+            uint32_t fh = (uint32_t)__builtin_ctz(x2 | 0x80000000u) >> 3;          // 0..3, 4 when x2 == 0 is handled below
+            fh = x2 ? fh : 4u;
+            const uint32_t f = x1 ? ((uint32_t)__builtin_ctz(x1) >> 3) : 4u + fh;
+            const uint32_t eq = x0 ? ((uint32_t)__builtin_clz(x0) >> 3) : 4u;
+            const bool m = valid & (x1 == 0u);
             uint32_t e2 = cur + f;
             e2 = e2 < L.mlimit ? e2 : L.mlimit;
             const uint32_t s3 = L.nb >> 6;
@@ -1099,32 +1109,34 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             const uint32_t nnext = ncur + nstep;
 
             // ---- next probe's data from the reservoir ----
-            uint32_t no = ncur - 2u - w.rb;
+            uint32_t no = ncur - 4u - w.rb;
             const bool sl = (no - 8u) < 8u;                   // slide by 8 bytes
             const uint32_t r0n = sl ? w.r2 : w.r0, r1n = sl ? w.r3 : w.r1, r2n = sl ? w.r4 : w.r2;
-            const uint32_t r3n = sl ? w.nx0 : w.r3, r4n = sl ? w.nx1 : w.r4;
+            const uint32_t r3n = sl ? w.r5 : w.r3, r4n = sl ? w.nx0 : w.r4, r5n = sl ? w.nx1 : w.r5;
             no -= sl ? 8u : 0u;
-            w.r0 = r0n; w.r1 = r1n; w.r2 = r2n; w.r3 = r3n; w.r4 = r4n; w.rb += sl ? 8u : 0u;
+            w.r0 = r0n; w.r1 = r1n; w.r2 = r2n; w.r3 = r3n; w.r4 = r4n; w.r5 = r5n; w.rb += sl ? 8u : 0u;
             const SnkBProbeData nd = snk_bextract(w, no & 7u);
 
             // ---- bookkeeping of this probe ----
             const uint32_t anchor0 = L.anchor, op0 = L.op;
-            const uint32_t lit = cur - anchor0;
-            const bool backeq = ((xlo & 0xFFu) == 0u) & (lit != 0u) & (cand != 0u);   // catch-up needed
-            const uint32_t mc = e2 - cur - 4u;
+            uint32_t lit = cur - anchor0;
+            uint32_t b = eq < lit ? eq : lit;
+            b = b < cand ? b : cand;
+            lit -= b;
             const uint32_t opn = op0 + lit + 3u;
-            const uint32_t big = lit > mc ? lit : mc;
-            const bool rare = m & (backeq | (f == 7u) | (big >= 15u) | (opn + 6u > L.olimit));
+            // rare: catch-up reaches 4, match reaches 8, literal run needs extension bytes, budget
+            // (match code = f + b - 4 <= 7 never needs extension bytes here)
+            const bool rare = m & ((b == 4u) | (f == 8u) | (lit >= 15u) | (opn > olim6));
+            const bool pre = (nnext > L.mfl1) | (no > 7u) | (ncur > w.lim);
             L.op = m ? opn : op0;
             L.anchor = m ? e2 : anchor0;
-            L.cur = ncur;
             L.step = nstep;
             L.nb = m ? 63u : L.nb + 1u;
+            L.cur = ncur;
             L.pending = m;
-            const bool pre = (nnext > L.mfl1) | (no > 7u) | (ncur > w.lim);
-            if (__builtin_expect(__any(rare | pre), 0)) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare | pre) != 0ull, 0)) {
                 if (rare) snk_bytes_match_slow(L, cur, cand, anchor0, op0);
-                const uint64_t rf = snk_ld8g(arena + (size_t)(w.soff + (w.rb + 20u - w.org)));
+                const uint64_t rf = snk_ld8g(arena + (size_t)(w.soff + (w.rb + 24u - w.org)));
                 w.nx0 = (uint32_t)rf; w.nx1 = (uint32_t)(rf >> 32);
                 break;
             }
@@ -1194,7 +1206,7 @@ __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_job
     L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos; L.endcode = 0;
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
-    L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.nx0 = L.w.nx1 = 0u;
+    L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
     snk_bytes_loop(L, T, tbl, bm, out, status);
 }
 
