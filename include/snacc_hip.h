@@ -63,6 +63,10 @@ void snk_ctx_destroy(snk_ctx *ctx);
 /* Tunables (all optional).  Keys:
  *   "fast_lanes"    chains (lanes) per wavefront in the 2-bit ACGT kernel
  *   "fast_waves"    wavefronts per workgroup in the 2-bit ACGT kernel
+ *   "bytes_lanes", "bytes_waves", "cbytes_lanes", "cbytes_waves"  the same for the byte kernels
+ *   "bytes_compact" -1 auto (default) / 0 never: compact table of the byte kernel when the
+ *                   resident sequences use <= 1024 distinct 5-byte hashes (set before upload)
+ *   "bytes_legacy"  1 = linked-mode byte jobs use the legacy u32-table kernel (testing)
  *   "force_generic" 1 = route every pair through the byte kernel (testing)
  *   "content_size"  1 = add the 8-byte content-size field to every frame
  *                   (py-lz4framed builds that set it)        */
@@ -76,9 +80,11 @@ int snk_set_option(snk_ctx *ctx, const char *key, long value);
  * A second upload on the same context replaces the first. */
 int snk_upload(snk_ctx *ctx, int n_seq, const uint8_t *const *seqs, const uint64_t *lens);
 
-/* Number of sequences resident / how many of them took the 2-bit path. */
+/* Number of sequences resident / how many of them took the 2-bit path / distinct 5-byte hash
+ * values in the resident set when the byte kernel can use its compact table (0 otherwise). */
 int snk_num_sequences(const snk_ctx *ctx);
 int snk_num_packed(const snk_ctx *ctx);
+int snk_num_compact_hashes(const snk_ctx *ctx);
 
 /* Phase A (ref:snacc/cli.py:108-116): sizes[i] = len(lz4framed.compress(seq_i)). */
 int snk_singles(snk_ctx *ctx, uint32_t *sizes /* [n_seq], host */);

@@ -27,6 +27,10 @@ struct snk_ctx_impl {
 
     // options
     int fast_lanes = 21, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;
+    int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel: up to 70 chains per CU
+    int bytes_compact_opt = -1;                // -1 auto, 0 never, 1 whenever the resident hash set allows
+    bool compact_ok = false;                   // the resident sequences use <= 1024 distinct 5-byte hashes
+    int n_hashes = 0;
     bool bytes_legacy = false;      // 1 = linked-mode byte jobs also go to the legacy u32-table kernel
     bool force_generic = false;
     uint32_t header_bytes = 7;
@@ -39,7 +43,7 @@ struct snk_ctx_impl {
     const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
-    uint16_t *d_lut_slot = nullptr; uint32_t *d_lut_hash = nullptr;
+    uint16_t *d_lut_slot = nullptr, *d_lut_h2c = nullptr; uint32_t *d_lut_hash = nullptr, *d_hashset = nullptr;
     uint32_t *d_single = nullptr, *d_status = nullptr;
     bool singles_done = false;
 
@@ -110,7 +114,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
-    T.lut_slot = c->d_lut_slot; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
+    T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
 
@@ -153,10 +157,28 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                            T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
-    if (n_bytes) {
+    if (n_bytes && c->compact_ok) {
+        const uint32_t lanes = (uint32_t)c->cbytes_lanes, waves = (uint32_t)c->cbytes_waves;
+        const uint32_t chains = lanes * waves;
+        const size_t lds = (size_t)SnkBT<true>::LUT_B + (size_t)chains * SnkBT<true>::CHAIN_B;
+        if (lds > 160 * 1024)
+            return fail(c, SNK_E_ARG, "cbytes_lanes*cbytes_waves = %u chains exceed the 160 KiB LDS (max 70)", chains);
+        HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_compact_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {   // the kernel addresses its hash LUT at LDS offset 0: that holds only without static LDS
+            hipFuncAttributes fa;
+            HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)snk_bytes_compact_kernel));
+            if (fa.sharedSizeBytes != 0)
+                return fail(c, SNK_E_STATE, "snk_bytes_compact_kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+        }
+        const uint32_t grid = (uint32_t)((n_bytes + chains - 1) / chains);
+        hipLaunchKernelGGL(snk_bytes_compact_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                           T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        HIPCHK(c, hipGetLastError());
+    } else if (n_bytes) {
         const uint32_t lanes = (uint32_t)c->bytes_lanes, waves = (uint32_t)c->bytes_waves;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)chains * SNK_BCHAIN_B;
+        const size_t lds = (size_t)chains * SnkBT<false>::CHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "bytes_lanes*bytes_waves = %u chains exceed the 160 KiB LDS (max 18)", chains);
         HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_kernel,
@@ -286,6 +308,8 @@ int snk_ctx_create(int device, snk_ctx **out)
             snk_ctx_destroy(c);
             return SNK_E_STATE;
         }
+        CRCHK(hipMalloc((void **)&c->d_lut_h2c, 4096 * sizeof(uint16_t)));
+        CRCHK(hipMalloc((void **)&c->d_hashset, 128 * sizeof(uint32_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_slot, 1024 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_hash, 1024 * sizeof(uint32_t)));
         CRCHK(hipMemcpy(c->d_lut_slot, slot.data(), 2048, hipMemcpyHostToDevice));
@@ -302,7 +326,7 @@ void snk_ctx_destroy(snk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_sequences(c);
-    dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_status);
+    dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_hashset); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -329,6 +353,15 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "bytes_waves") {
         if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "bytes_waves must be 1..16");
         c->bytes_waves = (int)value;
+    } else if (k == "cbytes_lanes") {
+        if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "cbytes_lanes must be 1..64");
+        c->cbytes_lanes = (int)value;
+    } else if (k == "cbytes_waves") {
+        if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "cbytes_waves must be 1..16");
+        c->cbytes_waves = (int)value;
+    } else if (k == "bytes_compact") {
+        if (c->n) return fail(c, SNK_E_STATE, "bytes_compact must be set before snk_upload");
+        c->bytes_compact_opt = (int)value;
     } else if (k == "bytes_legacy") {
         c->bytes_legacy = value != 0;
     } else if (k == "force_generic") {
@@ -344,6 +377,7 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
 
 int snk_num_sequences(const snk_ctx *c) { return c ? c->n : SNK_E_ARG; }
 int snk_num_packed(const snk_ctx *c) { return c ? c->n_packed : SNK_E_ARG; }
+int snk_num_compact_hashes(const snk_ctx *c) { return c ? (c->compact_ok ? c->n_hashes : 0) : SNK_E_ARG; }
 
 int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens)
 {
@@ -408,6 +442,41 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
                            c->d_bytes + boff[g], (uint64_t)lens[g], c->d_packed + poff[g]);
     }
     HIPCHK(c, hipGetLastError());
+
+    // ---- resident hash set: can the byte kernel use the compact table? --------------------------
+    c->compact_ok = false; c->n_hashes = 0;
+    if (c->bytes_compact_opt != 0 && !c->bytes_legacy) {
+        HIPCHK(c, hipMemsetAsync(c->d_hashset, 0, 128 * sizeof(uint32_t), c->stream));
+        bool any_packed = false, any_bytes = false;
+        for (size_t g = 0; g < n; ++g) {
+            if (c->is_packed[g] && !c->force_generic) { any_packed = true; continue; }   // contributes the 894 ACGT hashes
+            if (lens[g] < 5) continue;
+            any_bytes = true;
+            uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 1024);
+            hipLaunchKernelGGL(snk_hashset_kernel, dim3(grid), dim3(256), 0, c->stream,
+                               c->d_bytes + boff[g], (uint64_t)lens[g], c->d_hashset);
+        }
+        HIPCHK(c, hipGetLastError());
+        if (any_bytes || c->force_generic) {
+            uint32_t set[128];
+            HIPCHK(c, hipMemcpyAsync(set, c->d_hashset, sizeof set, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (any_packed) {
+                std::vector<uint16_t> slot; std::vector<uint32_t> hash;
+                build_luts(slot, hash);
+                for (uint32_t k = 0; k < 1024; ++k) set[hash[k] >> 5] |= 1u << (hash[k] & 31u);
+            }
+            std::vector<uint16_t> h2c(4096, 0xFFFF);
+            int cnt = 0;
+            for (uint32_t hsh = 0; hsh < 4096; ++hsh)
+                if (set[hsh >> 5] >> (hsh & 31u) & 1u) { if (cnt < 1024) h2c[hsh] = (uint16_t)cnt; cnt++; }
+            c->n_hashes = cnt;
+            if (cnt <= 1024) {
+                HIPCHK(c, hipMemcpy(c->d_lut_h2c, h2c.data(), 8192, hipMemcpyHostToDevice));
+                c->compact_ok = true;
+            }
+        }
+    }
 
     // ---- per-sequence tables ------------------------------------------------------------------
     std::vector<const uint8_t *> bp(n); std::vector<uint32_t> pp(n), bo(n);

@@ -54,6 +54,7 @@ struct SnkTables {
     uint32_t       *snap_fast;        // [n][896] slot indexed tables (ACGT sequences), absolute positions
     uint32_t       *snap_gen;         // [n][4096] hash indexed tables
     const uint16_t *lut_slot;         // [1024]  5-mer code -> table slot (0..893); colliding 5-mers share one
+    const uint16_t *lut_h2c;          // [4096]  compact byte kernel: hash -> slot 0..1023, 0xFFFF = not in the resident set
     const uint8_t  *zero_pad;         // >= 2*SNK_PAD zero bytes
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };
@@ -825,11 +826,22 @@ __global__ void snk_generic_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_j
 // full 4096-slot table, kept as 16-bit block offsets + "written this block" bitmap exactly like
 // the 2-bit kernel: 8712 B per chain -> 18 chains per CU (the u32 table of snk_generic_kernel
 // allows 8).  The slot is liblz4's 12-bit hash of 5 bytes, computed arithmetically.
-#define SNK_BSLOTS      4096u
-#define SNK_BDUMMY      4096u                    // extra slot that absorbs the put of "nothing owed"
-#define SNK_BTBL_B      ((SNK_BSLOTS + 2u) * 2u) // 8196
-#define SNK_BBMWORDS    129u
-#define SNK_BCHAIN_B    (SNK_BTBL_B + SNK_BBMWORDS * 4u)   // 8712 bytes
+// Two table geometries (template parameter COMPACT):
+//   full    : slot = hash (4096 slots + 1 dummy), 8712 B per chain -> 18 chains per CU.
+//   compact : when the 5-byte hashes that occur in ANY resident sequence number <= 1024 (upper-case
+//             ACGT with N runs and a few IUPAC codes: typically 900-1000), a shared LUT renames them
+//             to 0..1023 (exact: it is a renaming).  Only the <= 4 five-byte strings that span the
+//             x/y seam of a pair can hash outside that set; they get the chain-private slots
+//             1024..1027.  2196 B per chain (+ 8 KiB LUT per workgroup) -> 70 chains per CU.
+template <bool COMPACT> struct SnkBT {
+    static constexpr uint32_t SLOTS   = COMPACT ? 1028u : 4096u;    // real slots (compact: 1024 shared + 4 seam-private)
+    static constexpr uint32_t DUMMY   = COMPACT ? 1028u : 4096u;    // absorbs the put of "nothing owed"
+    static constexpr uint32_t TBL_B   = COMPACT ? 2064u : 8196u;    // bytes of the u16 table (1032 / 4098 entries)
+    static constexpr uint32_t BMWORDS = COMPACT ? 33u : 129u;
+    static constexpr uint32_t CHAIN_B = TBL_B + BMWORDS * 4u;        // 2196 / 8712
+    static constexpr uint32_t LUT_B   = COMPACT ? 8192u : 0u;        // hash -> slot LUT at LDS offset 0
+};
+#define SNK_BC_NOSLOT   0xFFFFu
 
 struct SnkByteSrc {
     snk_g8 *arena;            // wave-uniform base of the ASCII arena
@@ -917,6 +929,16 @@ struct SnkByteLane {
 // and the two table slots (5 bytes at cur and at cur-2).
 struct SnkBProbeData { SnkW12 w; uint32_t s1, s2; };
 
+// hash -> table slot (compact: through the LUT at LDS address 0; the kernel has no static LDS)
+template <bool COMPACT>
+__device__ __forceinline__ uint32_t snk_bslot(uint32_t h)
+{
+    if (!COMPACT) return h;
+    const __attribute__((address_space(3))) uint16_t *const lut = (const __attribute__((address_space(3))) uint16_t *)0;
+    return lut[h];
+}
+
+template <bool COMPACT>
 __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t o)
 {
     const bool hi = (o & 4u) != 0u;
@@ -927,11 +949,32 @@ __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t
     d.w.b = __builtin_amdgcn_alignbit(a2, a1, sh);       // bytes cur   .. cur+3
     d.w.c = __builtin_amdgcn_alignbit(a3, a2, sh);       // bytes cur+4 .. cur+7
     // 5 bytes at cur-2 = window bytes 2..6 ; 5 bytes at cur = window bytes 4..8
-    d.s2 = snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24));
-    d.s1 = snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8));
+    d.s2 = snk_bslot<COMPACT>(snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24)));
+    d.s1 = snk_bslot<COMPACT>(snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8)));
     return d;
 }
 
+// Slot of the 5 bytes at stream position p, for the slow paths (direct loads, seam aware).  In compact
+// mode a hash outside the resident set can only belong to a string spanning the seam (p in
+// [lx-4, lx-1]); equal seam hashes share one private slot, as they would share liblz4's.
+template <bool COMPACT>
+__device__ __forceinline__ uint32_t snk_bslot_slow(const SnkByteSrc &s, uint32_t p)
+{
+    const uint64_t w0 = snk_bld8(s, p);
+    const uint32_t h = snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
+    if (!COMPACT) return h;
+    const uint32_t id = snk_bslot<true>(h);
+    if (__builtin_expect(id != SNK_BC_NOSLOT, 1)) return id;
+    const int32_t j0 = (int32_t)s.lx - 4;                       // first seam-spanning position (may be < 0)
+    int32_t q = j0 < 0 ? 0 : j0;
+    for (; q < (int32_t)p; ++q) {
+        const uint64_t wq = snk_bld8(s, (uint32_t)q);
+        if (snk_hash5_parts((uint32_t)wq << 24, (uint32_t)(wq >> 8)) == h) break;
+    }
+    return 1024u + (uint32_t)(q - j0);
+}
+
+template <bool COMPACT>
 __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                      uint32_t *out, uint32_t *status)
 {
@@ -949,9 +992,16 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
     }
     for (;;) {
         if (L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
+            // prefix snapshot, always in liblz4's hash-indexed form (absolute positions, 0 = too far)
             uint32_t *dst = T.snap_gen + (size_t)L.xi * 4096u;
-            for (uint32_t t = 0; t < SNK_BSLOTS; ++t)
-                dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.pos - 65536u + tbl[t]) : 0u;
+            for (uint32_t h = 0; h < 4096u; ++h) {
+                const uint32_t t = snk_bslot<COMPACT>(h);
+                uint32_t v = 0u;
+                if (!COMPACT || t != SNK_BC_NOSLOT) {
+                    if ((bm[t >> 5] >> (t & 31u)) & 1u) v = L.pos - 65536u + tbl[t];
+                }
+                dst[h] = v;
+            }
             T.snap_out[L.xi] = L.total;
         }
         if (L.pos >= L.n) { out[L.out_idx] = L.total + 4u; return true; }
@@ -960,7 +1010,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.iend = L.pos + L.blen;
         if (L.blen < 13u) { L.total += 4u + L.blen; L.pos = L.iend; continue; }
         if (!L.first) {
-            for (uint32_t wi = 0; wi < SNK_BSLOTS / 32u; ++wi) {
+            for (uint32_t wi = 0; wi < (SnkBT<COMPACT>::SLOTS + 31u) / 32u; ++wi) {
                 uint32_t z = ~bm[wi];
                 while (z) {
                     const uint32_t b = (uint32_t)__builtin_ctz(z);
@@ -974,8 +1024,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.base = L.pos;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         {
-            const uint64_t w0 = snk_bld8(L.s, L.pos);
-            const uint32_t s0 = snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
+            const uint32_t s0 = snk_bslot_slow<COMPACT>(L.s, L.pos);
             tbl[s0] = 0;
             atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
         }
@@ -1016,10 +1065,11 @@ __device__ __forceinline__ void snk_bytes_match_slow(SnkByteLane &L, uint32_t cu
 }
 
 // table probe shared by the slow and the tight paths: returns candidate + validity, performs the puts
+template <bool COMPACT>
 __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *tbl, uint32_t *bm, uint32_t cur,
                                                 uint32_t s1, uint32_t s2, uint32_t &cand, bool &valid)
 {
-    s2 = L.pending ? s2 : SNK_BDUMMY;
+    s2 = L.pending ? s2 : SnkBT<COMPACT>::DUMMY;
     const uint32_t e = tbl[s1];
     const uint32_t bw = bm[s1 >> 5];
     const uint32_t c = cur - L.base;
@@ -1038,17 +1088,18 @@ __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *
 }
 
 // One fully general probe with direct loads (stream start, seam, after long jumps).
+template <bool COMPACT>
 __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                     uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur, next = cur + L.step;
-    if (next > L.mfl1) return snk_bytes_block_step(L, T, tbl, bm, out, status);
+    if (next > L.mfl1) return snk_bytes_block_step<COMPACT>(L, T, tbl, bm, out, status);
     const uint64_t wc = snk_bld8(L.s, cur);
-    const uint64_t wp = snk_bld8(L.s, cur - 2u);               // cur >= 1; at cur == 1 byte -1 is padding (unused: nothing owed)
-    const uint32_t s1 = snk_hash5_parts((uint32_t)wc << 24, (uint32_t)(wc >> 8));
-    const uint32_t s2 = snk_hash5_parts((uint32_t)wp << 24, (uint32_t)(wp >> 8));
+    const uint32_t s1 = snk_bslot_slow<COMPACT>(L.s, cur);
+    // the put of cur-2 is owed only after a match, which ends at least 5 positions into the block
+    const uint32_t s2 = L.pending ? snk_bslot_slow<COMPACT>(L.s, cur - 2u) : SnkBT<COMPACT>::DUMMY;
     uint32_t cand; bool valid;
-    snk_bytes_table(L, tbl, bm, cur, s1, s2, cand, valid);
+    snk_bytes_table<COMPACT>(L, tbl, bm, cur, s1, s2, cand, valid);
     const uint32_t s3 = L.nb >> 6;
     const uint64_t wd = snk_bld8(L.s, cand);
     if (valid && (uint32_t)wc == (uint32_t)wd) {
@@ -1065,6 +1116,7 @@ __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTab
 }
 
 // Tight loop.  Invariant at the head: (nx0, nx1) hold the bytes [rb+24, rb+32).
+template <bool COMPACT>
 __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                uint32_t *out, uint32_t *status)
 {
@@ -1078,14 +1130,14 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             o = cur - 4u - w.rb;
             const bool pre = (next > L.mfl1) | (o > 7u) | (cur > w.lim);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
-            if (pre && snk_bytes_iter_slow(L, T, tbl, bm, out, status)) return;
+            if (pre && snk_bytes_iter_slow<COMPACT>(L, T, tbl, bm, out, status)) return;
         }
-        SnkBProbeData d = snk_bextract(w, o);
+        SnkBProbeData d = snk_bextract<COMPACT>(w, o);
         const uint32_t olim6 = L.olimit - 6u;
 
         for (;;) {
             uint32_t cand; bool valid;
-            snk_bytes_table(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
+            snk_bytes_table<COMPACT>(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
 
             __builtin_amdgcn_sched_barrier(0);
             snk_g8 *nxp = arena + (size_t)(w.soff + (w.rb + 24u - w.org));
@@ -1115,7 +1167,8 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             const uint32_t r3n = sl ? w.r5 : w.r3, r4n = sl ? w.nx0 : w.r4, r5n = sl ? w.nx1 : w.r5;
             no -= sl ? 8u : 0u;
             w.r0 = r0n; w.r1 = r1n; w.r2 = r2n; w.r3 = r3n; w.r4 = r4n; w.r5 = r5n; w.rb += sl ? 8u : 0u;
-            const SnkBProbeData nd = snk_bextract(w, no & 7u);
+            const SnkBProbeData nd = snk_bextract<COMPACT>(w, no & 7u);
+            if (COMPACT) __builtin_amdgcn_sched_barrier(0);   // keep the LUT reads in front of the bookkeeping
 
             // ---- bookkeeping of this probe ----
             const uint32_t anchor0 = L.anchor, op0 = L.op;
@@ -1145,10 +1198,12 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
     }
 }
 
-// grid: one workgroup per `lanes*waves` jobs; dynamic LDS = 8712 B per chain.
-__global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
-                                 uint32_t lanes, uint32_t *out, uint32_t *status)
+// grid: one workgroup per `lanes*waves` jobs; dynamic LDS = LUT_B + CHAIN_B per chain.
+template <bool COMPACT>
+__device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
+                                                      uint32_t lanes, uint32_t *out, uint32_t *status)
 {
+    typedef SnkBT<COMPACT> G;
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
@@ -1156,8 +1211,13 @@ __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_job
     const uint32_t c = lane * waves + wave;
     const uint32_t j = blockIdx.x * chains + c;
     const bool active = lane < lanes && j < n_jobs;
-    uint8_t *mine = snk_lds8 + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * SNK_BCHAIN_B;
+    uint8_t *mine = snk_lds8 + G::LUT_B + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * G::CHAIN_B;
 
+    if (COMPACT) {
+        for (uint32_t t = tid; t < 2048u; t += blockDim.x)
+            ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_h2c)[t];
+        __syncthreads();
+    }
     SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
     if (active) job = jobs[j];
 
@@ -1166,28 +1226,41 @@ __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_job
         const int xi  = __shfl(job.xi, (int)l);
         const int snp = __shfl(job.snap, (int)l);
         if (!a) continue;
-        uint8_t *dst = snk_lds8 + (size_t)(wave * lanes + l) * SNK_BCHAIN_B;
+        uint8_t *dst = snk_lds8 + G::LUT_B + (size_t)(wave * lanes + l) * G::CHAIN_B;
         const uint32_t spos = T.snap_pos[xi];
         const bool use = (snp == 0) && (spos != 0u);
         const uint32_t *src = T.snap_gen + (size_t)xi * 4096u;
-        for (uint32_t t = lane; t < SNK_BTBL_B / 4u; t += 64u) {
-            uint32_t v = 0u;
-            if (use && t < SNK_BSLOTS / 2u) {
-                const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
-                const uint32_t lo = (a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u;
-                const uint32_t hi = (a1 + 65536u >= spos) ? (a1 & 0xFFFFu) : 0u;
-                v = lo | (hi << 16);
+        if (!COMPACT) {
+            for (uint32_t t = lane; t < G::TBL_B / 4u; t += 64u) {
+                uint32_t v = 0u;
+                if (use && t < 2048u) {
+                    const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
+                    const uint32_t lo = (a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u;
+                    const uint32_t hi = (a1 + 65536u >= spos) ? (a1 & 0xFFFFu) : 0u;
+                    v = lo | (hi << 16);
+                }
+                ((uint32_t *)dst)[t] = v;
             }
-            ((uint32_t *)dst)[t] = v;
+        } else {
+            for (uint32_t t = lane; t < G::TBL_B / 4u; t += 64u) ((uint32_t *)dst)[t] = 0u;
+            if (use) {
+                // scatter liblz4's hash-indexed snapshot into the renamed slots (LDS ops of a wave are
+                // executed in issue order, so the zero fill above lands first)
+                for (uint32_t h = lane; h < 4096u; h += 64u) {
+                    const uint32_t id = snk_bslot<true>(h);
+                    const uint32_t a0 = src[h];
+                    if (id != SNK_BC_NOSLOT) ((uint16_t *)dst)[id] = (uint16_t)((a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u);
+                }
+            }
         }
-        for (uint32_t t = lane; t < SNK_BBMWORDS; t += 64u)
-            ((uint32_t *)(dst + SNK_BTBL_B))[t] = use ? 0u : 0xFFFFFFFFu;
+        for (uint32_t t = lane; t < G::BMWORDS; t += 64u)
+            ((uint32_t *)(dst + G::TBL_B))[t] = use ? 0u : 0xFFFFFFFFu;
     }
     __syncthreads();
     if (!active) return;
 
     uint16_t *tbl = (uint16_t *)mine;
-    uint32_t *bm = (uint32_t *)(mine + SNK_BTBL_B);
+    uint32_t *bm = (uint32_t *)(mine + G::TBL_B);
     SnkByteLane L;
     const uint32_t lx = T.len[job.xi];
     const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
@@ -1207,7 +1280,19 @@ __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_job
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
     L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
-    snk_bytes_loop(L, T, tbl, bm, out, status);
+    snk_bytes_loop<COMPACT>(L, T, tbl, bm, out, status);
+}
+
+__global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                 uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<false>(T, jobs, n_jobs, lanes, out, status);
+}
+
+__global__ void snk_bytes_compact_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                         uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<true>(T, jobs, n_jobs, lanes, out, status);
 }
 
 // =========================================================================
@@ -1242,6 +1327,29 @@ __global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packe
         }
         packed[o] = (uint8_t)v;
     }
+}
+
+// Which of liblz4's 4096 hash values occur inside one sequence (5 bytes at every position p <= n-5).
+// One 4096-bit set per launch target, OR-ed into `set` (128 words).
+__global__ void snk_hashset_kernel(const uint8_t *bytes, uint64_t n, uint32_t *set)
+{
+    __shared__ uint32_t local[128];
+    for (uint32_t t = threadIdx.x; t < 128u; t += blockDim.x) local[t] = 0u;
+    __syncthreads();
+    if (n >= 5) {
+        const uint64_t last = n - 5;
+        uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (; p <= last; p += stride) {
+            uint64_t v = 0;
+            for (uint32_t b = 0; b < 5u; ++b) v |= (uint64_t)bytes[p + b] << (8u * b);
+            const uint32_t h = (uint32_t)(((v << 24) * 889523592379ull) >> 52);
+            atomicOr(&local[h >> 5], 1u << (h & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 128u; t += blockDim.x)
+        if (local[t]) atomicOr(&set[t], local[t]);
 }
 
 // slot-indexed snapshot -> hash-indexed snapshot (for ACGT prefix + non-ACGT suffix pairs)

@@ -19,7 +19,7 @@ ABI_VERSION = 1
 #: every symbol ``include/snacc_hip.h`` declares (checked by the CPU test-suite)
 EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
-    "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_singles", "snk_pairs",
+    "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_sync", "snk_last_pairs_ms",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
 )
@@ -83,6 +83,8 @@ def load():
     L.snk_num_sequences.argtypes = [vp]
     L.snk_num_packed.restype = i32
     L.snk_num_packed.argtypes = [vp]
+    L.snk_num_compact_hashes.restype = i32
+    L.snk_num_compact_hashes.argtypes = [vp]
     L.snk_singles.restype = i32
     L.snk_singles.argtypes = [vp, u32p]
     L.snk_pairs.restype = i32
@@ -216,6 +218,11 @@ class HipContext:
     @property
     def num_packed(self):
         return self._L.snk_num_packed(self._h)
+
+    @property
+    def num_compact_hashes(self):
+        """> 0 when the byte kernel runs with its compact table (that many distinct 5-byte hashes)."""
+        return self._L.snk_num_compact_hashes(self._h)
 
     # -- phase A / B --------------------------------------------------------------------
     def singles(self):

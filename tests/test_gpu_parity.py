@@ -40,7 +40,8 @@ def test_tiny_and_empty_inputs(hip, oracle_mod):
 def test_lcg_100k_fast_and_generic_paths(hip, oracle_mod):
     seqs = [oracle_mod.lcg_genome(1 + i, 100000) for i in range(6)]
     assert _check_all(hip, oracle_mod, seqs) == 6
-    _check_all(hip, oracle_mod, seqs, force_generic=1)                      # tight-loop byte kernel
+    _check_all(hip, oracle_mod, seqs, force_generic=1)                      # tight-loop byte kernel (compact table)
+    _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_compact=0)     # same, full 4096-slot table
     _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_legacy=1)      # legacy u32-table byte kernel
     _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_lanes=4, bytes_waves=3)
 
@@ -74,6 +75,48 @@ def test_byte_kernel_on_everything(hip, oracle_mod):
              np.frombuffer(b"A" * 150000, dtype=np.uint8), np.frombuffer(b"AC" * 60000, dtype=np.uint8),
              np.frombuffer(b"N" * 1000 + bytes(o.lcg_genome(77, 90000)) + b"n" * 3000, dtype=np.uint8)]
     _check_all(hip, oracle_mod, seqs, force_generic=1)
+    _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_compact=0)
+
+
+def test_compact_byte_kernel_seam_strings(hip, oracle_mod):
+    """Mostly-ACGT genomes with N runs: the byte kernel runs with its compact table (<= 1024 distinct
+    5-byte hashes).  Sequence ends/starts are chosen so that the 5-byte strings spanning the x/y seam
+    hash OUTSIDE the resident set (chain-private slots), including identical seam strings."""
+    o = oracle_mod
+
+    def g(seed, n):
+        return bytes(o.lcg_genome(seed, n))
+    seqs = [
+        g(1, 90000) + b"NNNN",                         # ends in N: seam strings NNNN+?, ...
+        b"NNNN" + g(2, 80000),                         # starts with N: with the one above -> NNNNN x4 (shared slot)
+        g(3, 70000) + b"N" * 300 + g(4, 40000) + b"RY",
+        b"K" + g(5, 100000),
+        g(6, 120000),                                   # pure ACGT (2-bit path with itself)
+        g(7, 66000) + b"NNN",
+        b"NN" + g(8, 66000) + b"NNNNN" + g(9, 3000),
+        g(10, 65536),                                   # exactly one block
+        b"N" * 70000,
+    ]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert 894 <= ctx.num_compact_hashes <= 1024
+        s, p = ctx.singles(), ctx.pairs()
+    exp_s = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    assert np.array_equal(s, exp_s)
+    assert np.array_equal(p, exp_p)
+    with hip.HipContext(0, bytes_compact=0) as ctx:     # the full table gives the same
+        ctx.upload(seqs)
+        assert ctx.num_compact_hashes == 0
+        assert np.array_equal(ctx.pairs(), exp_p)
+
+
+def test_compact_falls_back_when_too_many_hashes(hip, oracle_mod):
+    rng = np.random.default_rng(3)
+    seqs = [oracle_mod.lcg_genome(1, 100000), rng.integers(0, 256, 100000, dtype=np.uint8)]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert ctx.num_compact_hashes == 0              # > 1024 distinct hashes: full table
 
 
 def test_long_matches_and_low_complexity(hip, oracle_mod):
