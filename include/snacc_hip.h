@@ -63,9 +63,10 @@ void snk_ctx_destroy(snk_ctx *ctx);
 /* Tunables (all optional).  Keys:
  *   "fast_lanes"    chains (lanes) per wavefront in the 2-bit ACGT kernel
  *   "fast_waves"    wavefronts per workgroup in the 2-bit ACGT kernel
- *   "bytes_lanes", "bytes_waves", "cbytes_lanes", "cbytes_waves"  the same for the byte kernels
+ *   "bytes_lanes", "bytes_waves", "cbytes_*", "c2bytes_*"  the same for the byte kernels
+ *                   (full table / compact 1024 slots / compact 2048 slots)
  *   "bytes_compact" -1 auto (default) / 0 never: compact table of the byte kernel when the
- *                   resident sequences use <= 1024 distinct 5-byte hashes (set before upload)
+ *                   resident sequences use <= 2048 distinct 5-byte hashes (set before upload)
  *   "bytes_legacy"  1 = linked-mode byte jobs use the legacy u32-table kernel (testing)
  *   "force_generic" 1 = route every pair through the byte kernel (testing)
  *   "content_size"  1 = add the 8-byte content-size field to every frame

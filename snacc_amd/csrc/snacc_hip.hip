@@ -27,9 +27,11 @@ struct snk_ctx_impl {
 
     // options
     int fast_lanes = 21, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;
-    int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel: up to 70 chains per CU
+    int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
+    int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
+    int compact_cap = 0;                       // 0 / 1024 / 2048
     int bytes_compact_opt = -1;                // -1 auto, 0 never, 1 whenever the resident hash set allows
-    bool compact_ok = false;                   // the resident sequences use <= 1024 distinct 5-byte hashes
+    bool compact_ok = false;                   // the resident sequences use <= 2048 distinct 5-byte hashes
     int n_hashes = 0;
     bool bytes_legacy = false;      // 1 = linked-mode byte jobs also go to the legacy u32-table kernel
     bool force_generic = false;
@@ -158,27 +160,34 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         HIPCHK(c, hipGetLastError());
     }
     if (n_bytes && c->compact_ok) {
-        const uint32_t lanes = (uint32_t)c->cbytes_lanes, waves = (uint32_t)c->cbytes_waves;
+        const bool big = c->compact_cap == 2048;
+        const uint32_t lanes = (uint32_t)(big ? c->c2bytes_lanes : c->cbytes_lanes);
+        const uint32_t waves = (uint32_t)(big ? c->c2bytes_waves : c->cbytes_waves);
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)SnkBT<true>::LUT_B + (size_t)chains * SnkBT<true>::CHAIN_B;
+        const size_t chain_b = big ? SnkBT<2048>::CHAIN_B : SnkBT<1024>::CHAIN_B;
+        const size_t lds = (size_t)SnkBT<1024>::LUT_B + (size_t)chains * chain_b;
+        const void *kern = big ? (const void *)snk_bytes_compact2k_kernel : (const void *)snk_bytes_compact_kernel;
         if (lds > 160 * 1024)
-            return fail(c, SNK_E_ARG, "cbytes_lanes*cbytes_waves = %u chains exceed the 160 KiB LDS (max 70)", chains);
-        HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_compact_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return fail(c, SNK_E_ARG, "%u compact byte chains exceed the 160 KiB LDS (max %d)", chains, big ? 35 : 70);
+        HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {   // the kernel addresses its hash LUT at LDS offset 0: that holds only without static LDS
             hipFuncAttributes fa;
-            HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)snk_bytes_compact_kernel));
+            HIPCHK(c, hipFuncGetAttributes(&fa, kern));
             if (fa.sharedSizeBytes != 0)
-                return fail(c, SNK_E_STATE, "snk_bytes_compact_kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+                return fail(c, SNK_E_STATE, "compact byte kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
         }
         const uint32_t grid = (uint32_t)((n_bytes + chains - 1) / chains);
-        hipLaunchKernelGGL(snk_bytes_compact_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                           T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        if (big)
+            hipLaunchKernelGGL(snk_bytes_compact2k_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        else
+            hipLaunchKernelGGL(snk_bytes_compact_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     } else if (n_bytes) {
         const uint32_t lanes = (uint32_t)c->bytes_lanes, waves = (uint32_t)c->bytes_waves;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)chains * SnkBT<false>::CHAIN_B;
+        const size_t lds = (size_t)chains * SnkBT<0>::CHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "bytes_lanes*bytes_waves = %u chains exceed the 160 KiB LDS (max 18)", chains);
         HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_kernel,
@@ -359,6 +368,12 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "cbytes_waves") {
         if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "cbytes_waves must be 1..16");
         c->cbytes_waves = (int)value;
+    } else if (k == "c2bytes_lanes") {
+        if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "c2bytes_lanes must be 1..64");
+        c->c2bytes_lanes = (int)value;
+    } else if (k == "c2bytes_waves") {
+        if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "c2bytes_waves must be 1..16");
+        c->c2bytes_waves = (int)value;
     } else if (k == "bytes_compact") {
         if (c->n) return fail(c, SNK_E_STATE, "bytes_compact must be set before snk_upload");
         c->bytes_compact_opt = (int)value;
@@ -444,7 +459,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipGetLastError());
 
     // ---- resident hash set: can the byte kernel use the compact table? --------------------------
-    c->compact_ok = false; c->n_hashes = 0;
+    c->compact_ok = false; c->n_hashes = 0; c->compact_cap = 0;
     if (c->bytes_compact_opt != 0 && !c->bytes_legacy) {
         HIPCHK(c, hipMemsetAsync(c->d_hashset, 0, 128 * sizeof(uint32_t), c->stream));
         bool any_packed = false, any_bytes = false;
@@ -469,11 +484,12 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
             std::vector<uint16_t> h2c(4096, 0xFFFF);
             int cnt = 0;
             for (uint32_t hsh = 0; hsh < 4096; ++hsh)
-                if (set[hsh >> 5] >> (hsh & 31u) & 1u) { if (cnt < 1024) h2c[hsh] = (uint16_t)cnt; cnt++; }
+                if (set[hsh >> 5] >> (hsh & 31u) & 1u) { if (cnt < 2048) h2c[hsh] = (uint16_t)cnt; cnt++; }
             c->n_hashes = cnt;
-            if (cnt <= 1024) {
+            if (cnt <= 2048) {
                 HIPCHK(c, hipMemcpy(c->d_lut_h2c, h2c.data(), 8192, hipMemcpyHostToDevice));
                 c->compact_ok = true;
+                c->compact_cap = cnt <= 1024 ? 1024 : 2048;
             }
         }
     }

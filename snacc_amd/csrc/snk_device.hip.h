@@ -829,17 +829,19 @@ __global__ void snk_generic_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_j
 // Two table geometries (template parameter COMPACT):
 //   full    : slot = hash (4096 slots + 1 dummy), 8712 B per chain -> 18 chains per CU.
 //   compact : when the 5-byte hashes that occur in ANY resident sequence number <= 1024 (upper-case
-//             ACGT with N runs and a few IUPAC codes: typically 900-1000), a shared LUT renames them
-//             to 0..1023 (exact: it is a renaming).  Only the <= 4 five-byte strings that span the
+//             ACGT with N runs and a few IUPAC codes: typically 900-1000) or <= 2048 (soft-masked
+//             genomes), a shared LUT renames them to 0..CAP-1 (exact: it is a renaming).  Only the <= 4 five-byte strings that span the
 //             x/y seam of a pair can hash outside that set; they get the chain-private slots
-//             1024..1027.  2196 B per chain (+ 8 KiB LUT per workgroup) -> 70 chains per CU.
-template <bool COMPACT> struct SnkBT {
-    static constexpr uint32_t SLOTS   = COMPACT ? 1028u : 4096u;    // real slots (compact: 1024 shared + 4 seam-private)
-    static constexpr uint32_t DUMMY   = COMPACT ? 1028u : 4096u;    // absorbs the put of "nothing owed"
-    static constexpr uint32_t TBL_B   = COMPACT ? 2064u : 8196u;    // bytes of the u16 table (1032 / 4098 entries)
-    static constexpr uint32_t BMWORDS = COMPACT ? 33u : 129u;
-    static constexpr uint32_t CHAIN_B = TBL_B + BMWORDS * 4u;        // 2196 / 8712
-    static constexpr uint32_t LUT_B   = COMPACT ? 8192u : 0u;        // hash -> slot LUT at LDS offset 0
+//             CAP..CAP+3.  2196 / 4380 B per chain (+ 8 KiB LUT per workgroup) -> 70 / 35 chains per CU.
+template <int CAP> struct SnkBT {                                 // CAP: 0 = full table, 1024 / 2048 = compact capacity
+    static constexpr bool     COMPACT = CAP != 0;
+    static constexpr uint32_t SEAM0   = (uint32_t)CAP;                  // first of the 4 seam-private slots
+    static constexpr uint32_t SLOTS   = COMPACT ? (uint32_t)CAP + 4u : 4096u;   // real slots
+    static constexpr uint32_t DUMMY   = SLOTS;                          // absorbs the put of "nothing owed"
+    static constexpr uint32_t TBL_B   = ((SLOTS + 1u + 3u) / 4u) * 8u;  // u16 entries, rounded to 8 bytes
+    static constexpr uint32_t BMWORDS = (SLOTS + 1u + 31u) / 32u;
+    static constexpr uint32_t CHAIN_B = TBL_B + BMWORDS * 4u;           // 2196 (1024) / 4380 (2048) / 8716 (full)
+    static constexpr uint32_t LUT_B   = COMPACT ? 8192u : 0u;           // hash -> slot LUT at LDS offset 0
 };
 #define SNK_BC_NOSLOT   0xFFFFu
 
@@ -938,7 +940,7 @@ __device__ __forceinline__ uint32_t snk_bslot(uint32_t h)
     return lut[h];
 }
 
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t o)
 {
     const bool hi = (o & 4u) != 0u;
@@ -949,20 +951,20 @@ __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t
     d.w.b = __builtin_amdgcn_alignbit(a2, a1, sh);       // bytes cur   .. cur+3
     d.w.c = __builtin_amdgcn_alignbit(a3, a2, sh);       // bytes cur+4 .. cur+7
     // 5 bytes at cur-2 = window bytes 2..6 ; 5 bytes at cur = window bytes 4..8
-    d.s2 = snk_bslot<COMPACT>(snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24)));
-    d.s1 = snk_bslot<COMPACT>(snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8)));
+    d.s2 = snk_bslot<(CAP != 0)>(snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24)));
+    d.s1 = snk_bslot<(CAP != 0)>(snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8)));
     return d;
 }
 
 // Slot of the 5 bytes at stream position p, for the slow paths (direct loads, seam aware).  In compact
 // mode a hash outside the resident set can only belong to a string spanning the seam (p in
 // [lx-4, lx-1]); equal seam hashes share one private slot, as they would share liblz4's.
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ uint32_t snk_bslot_slow(const SnkByteSrc &s, uint32_t p)
 {
     const uint64_t w0 = snk_bld8(s, p);
     const uint32_t h = snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
-    if (!COMPACT) return h;
+    if (CAP == 0) return h;
     const uint32_t id = snk_bslot<true>(h);
     if (__builtin_expect(id != SNK_BC_NOSLOT, 1)) return id;
     const int32_t j0 = (int32_t)s.lx - 4;                       // first seam-spanning position (may be < 0)
@@ -971,10 +973,10 @@ __device__ __forceinline__ uint32_t snk_bslot_slow(const SnkByteSrc &s, uint32_t
         const uint64_t wq = snk_bld8(s, (uint32_t)q);
         if (snk_hash5_parts((uint32_t)wq << 24, (uint32_t)(wq >> 8)) == h) break;
     }
-    return 1024u + (uint32_t)(q - j0);
+    return SnkBT<CAP>::SEAM0 + (uint32_t)(q - j0);
 }
 
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                      uint32_t *out, uint32_t *status)
 {
@@ -995,9 +997,9 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
             // prefix snapshot, always in liblz4's hash-indexed form (absolute positions, 0 = too far)
             uint32_t *dst = T.snap_gen + (size_t)L.xi * 4096u;
             for (uint32_t h = 0; h < 4096u; ++h) {
-                const uint32_t t = snk_bslot<COMPACT>(h);
+                const uint32_t t = snk_bslot<(CAP != 0)>(h);
                 uint32_t v = 0u;
-                if (!COMPACT || t != SNK_BC_NOSLOT) {
+                if (CAP == 0 || t != SNK_BC_NOSLOT) {
                     if ((bm[t >> 5] >> (t & 31u)) & 1u) v = L.pos - 65536u + tbl[t];
                 }
                 dst[h] = v;
@@ -1010,7 +1012,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.iend = L.pos + L.blen;
         if (L.blen < 13u) { L.total += 4u + L.blen; L.pos = L.iend; continue; }
         if (!L.first) {
-            for (uint32_t wi = 0; wi < (SnkBT<COMPACT>::SLOTS + 31u) / 32u; ++wi) {
+            for (uint32_t wi = 0; wi < (SnkBT<CAP>::SLOTS + 31u) / 32u; ++wi) {
                 uint32_t z = ~bm[wi];
                 while (z) {
                     const uint32_t b = (uint32_t)__builtin_ctz(z);
@@ -1024,7 +1026,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.base = L.pos;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         {
-            const uint32_t s0 = snk_bslot_slow<COMPACT>(L.s, L.pos);
+            const uint32_t s0 = snk_bslot_slow<CAP>(L.s, L.pos);
             tbl[s0] = 0;
             atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
         }
@@ -1065,11 +1067,11 @@ __device__ __forceinline__ void snk_bytes_match_slow(SnkByteLane &L, uint32_t cu
 }
 
 // table probe shared by the slow and the tight paths: returns candidate + validity, performs the puts
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *tbl, uint32_t *bm, uint32_t cur,
                                                 uint32_t s1, uint32_t s2, uint32_t &cand, bool &valid)
 {
-    s2 = L.pending ? s2 : SnkBT<COMPACT>::DUMMY;
+    s2 = L.pending ? s2 : SnkBT<CAP>::DUMMY;
     const uint32_t e = tbl[s1];
     const uint32_t bw = bm[s1 >> 5];
     const uint32_t c = cur - L.base;
@@ -1088,18 +1090,18 @@ __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *
 }
 
 // One fully general probe with direct loads (stream start, seam, after long jumps).
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                     uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur, next = cur + L.step;
-    if (next > L.mfl1) return snk_bytes_block_step<COMPACT>(L, T, tbl, bm, out, status);
+    if (next > L.mfl1) return snk_bytes_block_step<CAP>(L, T, tbl, bm, out, status);
     const uint64_t wc = snk_bld8(L.s, cur);
-    const uint32_t s1 = snk_bslot_slow<COMPACT>(L.s, cur);
+    const uint32_t s1 = snk_bslot_slow<CAP>(L.s, cur);
     // the put of cur-2 is owed only after a match, which ends at least 5 positions into the block
-    const uint32_t s2 = L.pending ? snk_bslot_slow<COMPACT>(L.s, cur - 2u) : SnkBT<COMPACT>::DUMMY;
+    const uint32_t s2 = L.pending ? snk_bslot_slow<CAP>(L.s, cur - 2u) : SnkBT<CAP>::DUMMY;
     uint32_t cand; bool valid;
-    snk_bytes_table<COMPACT>(L, tbl, bm, cur, s1, s2, cand, valid);
+    snk_bytes_table<CAP>(L, tbl, bm, cur, s1, s2, cand, valid);
     const uint32_t s3 = L.nb >> 6;
     const uint64_t wd = snk_bld8(L.s, cand);
     if (valid && (uint32_t)wc == (uint32_t)wd) {
@@ -1116,7 +1118,7 @@ __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTab
 }
 
 // Tight loop.  Invariant at the head: (nx0, nx1) hold the bytes [rb+24, rb+32).
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                uint32_t *out, uint32_t *status)
 {
@@ -1130,14 +1132,14 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             o = cur - 4u - w.rb;
             const bool pre = (next > L.mfl1) | (o > 7u) | (cur > w.lim);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
-            if (pre && snk_bytes_iter_slow<COMPACT>(L, T, tbl, bm, out, status)) return;
+            if (pre && snk_bytes_iter_slow<CAP>(L, T, tbl, bm, out, status)) return;
         }
-        SnkBProbeData d = snk_bextract<COMPACT>(w, o);
+        SnkBProbeData d = snk_bextract<CAP>(w, o);
         const uint32_t olim6 = L.olimit - 6u;
 
         for (;;) {
             uint32_t cand; bool valid;
-            snk_bytes_table<COMPACT>(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
+            snk_bytes_table<CAP>(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
 
             __builtin_amdgcn_sched_barrier(0);
             snk_g8 *nxp = arena + (size_t)(w.soff + (w.rb + 24u - w.org));
@@ -1167,8 +1169,8 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             const uint32_t r3n = sl ? w.r5 : w.r3, r4n = sl ? w.nx0 : w.r4, r5n = sl ? w.nx1 : w.r5;
             no -= sl ? 8u : 0u;
             w.r0 = r0n; w.r1 = r1n; w.r2 = r2n; w.r3 = r3n; w.r4 = r4n; w.r5 = r5n; w.rb += sl ? 8u : 0u;
-            const SnkBProbeData nd = snk_bextract<COMPACT>(w, no & 7u);
-            if (COMPACT) __builtin_amdgcn_sched_barrier(0);   // keep the LUT reads in front of the bookkeeping
+            const SnkBProbeData nd = snk_bextract<CAP>(w, no & 7u);
+            if (CAP != 0) __builtin_amdgcn_sched_barrier(0);   // keep the LUT reads in front of the bookkeeping
 
             // ---- bookkeeping of this probe ----
             const uint32_t anchor0 = L.anchor, op0 = L.op;
@@ -1199,11 +1201,11 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
 }
 
 // grid: one workgroup per `lanes*waves` jobs; dynamic LDS = LUT_B + CHAIN_B per chain.
-template <bool COMPACT>
+template <int CAP>
 __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
                                                       uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    typedef SnkBT<COMPACT> G;
+    typedef SnkBT<CAP> G;
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
@@ -1213,7 +1215,7 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     const bool active = lane < lanes && j < n_jobs;
     uint8_t *mine = snk_lds8 + G::LUT_B + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * G::CHAIN_B;
 
-    if (COMPACT) {
+    if (CAP != 0) {
         for (uint32_t t = tid; t < 2048u; t += blockDim.x)
             ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_h2c)[t];
         __syncthreads();
@@ -1230,7 +1232,7 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
         const uint32_t spos = T.snap_pos[xi];
         const bool use = (snp == 0) && (spos != 0u);
         const uint32_t *src = T.snap_gen + (size_t)xi * 4096u;
-        if (!COMPACT) {
+        if (CAP == 0) {
             for (uint32_t t = lane; t < G::TBL_B / 4u; t += 64u) {
                 uint32_t v = 0u;
                 if (use && t < 2048u) {
@@ -1280,19 +1282,25 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
     L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
-    snk_bytes_loop<COMPACT>(L, T, tbl, bm, out, status);
+    snk_bytes_loop<CAP>(L, T, tbl, bm, out, status);
 }
 
 __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                  uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_bytes_kernel_body<false>(T, jobs, n_jobs, lanes, out, status);
+    snk_bytes_kernel_body<0>(T, jobs, n_jobs, lanes, out, status);
 }
 
 __global__ void snk_bytes_compact_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                          uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_bytes_kernel_body<true>(T, jobs, n_jobs, lanes, out, status);
+    snk_bytes_kernel_body<1024>(T, jobs, n_jobs, lanes, out, status);
+}
+
+__global__ void snk_bytes_compact2k_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                           uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<2048>(T, jobs, n_jobs, lanes, out, status);
 }
 
 // =========================================================================

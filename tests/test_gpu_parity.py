@@ -111,6 +111,30 @@ def test_compact_byte_kernel_seam_strings(hip, oracle_mod):
         assert np.array_equal(ctx.pairs(), exp_p)
 
 
+def test_compact_2048_soft_masked_genomes(hip, oracle_mod):
+    """Soft-masked genomes (upper + lower case + N runs): ~1900 distinct 5-byte hashes -> the
+    2048-slot compact table."""
+    o = oracle_mod
+    rng = np.random.default_rng(8)
+
+    def soft(seed, n):
+        g = bytearray(bytes(o.lcg_genome(seed, n)))
+        for start in rng.integers(0, n - 3000, 12):
+            ln = int(rng.integers(50, 2500))
+            g[start:start + ln] = bytes(g[start:start + ln]).lower()
+        for start in rng.integers(0, n - 500, 3):
+            g[start:start + int(rng.integers(1, 300))] = b"N" * int(rng.integers(1, 300))
+        return bytes(g)
+    seqs = [soft(1, 120000), soft(2, 90000), soft(3, 140000), bytes(o.lcg_genome(4, 100000)).lower(),
+            bytes(o.lcg_genome(5, 100000))]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert 1024 < ctx.num_compact_hashes <= 2048
+        s, p = ctx.singles(), ctx.pairs()
+    assert np.array_equal(s, np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32))
+    assert np.array_equal(p, np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32))
+
+
 def test_compact_falls_back_when_too_many_hashes(hip, oracle_mod):
     rng = np.random.default_rng(3)
     seqs = [oracle_mod.lcg_genome(1, 100000), rng.integers(0, 256, 100000, dtype=np.uint8)]
