@@ -30,6 +30,9 @@ struct snk_ctx_impl {
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
     int compact_cap = 0;                       // 0 / 1024 / 2048
+    int os_lanes = 9, os_waves = 1;            // one-shot kernel, full 8192-slot table: 9 chains per CU
+    int cos_lanes = 16, cos_waves = 4;         // one-shot kernel, compact table: up to 67 chains per CU
+    bool oneshot_compact_ok = false; int n_hashes4 = 0;
     int bytes_compact_opt = -1;                // -1 auto, 0 never, 1 whenever the resident hash set allows
     bool compact_ok = false;                   // the resident sequences use <= 2048 distinct 5-byte hashes
     int n_hashes = 0;
@@ -45,7 +48,8 @@ struct snk_ctx_impl {
     const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
-    uint16_t *d_lut_slot = nullptr, *d_lut_h2c = nullptr; uint32_t *d_lut_hash = nullptr, *d_hashset = nullptr;
+    uint16_t *d_lut_slot = nullptr, *d_lut_h2c = nullptr, *d_lut_h2c4 = nullptr;
+    uint32_t *d_lut_hash = nullptr, *d_hashset = nullptr;      // d_hashset: 128 words (hash5) + 256 words (hash4)
     uint32_t *d_single = nullptr, *d_status = nullptr;
     bool singles_done = false;
 
@@ -116,7 +120,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
-    T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
+    T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
 
@@ -164,8 +168,8 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const uint32_t lanes = (uint32_t)(big ? c->c2bytes_lanes : c->cbytes_lanes);
         const uint32_t waves = (uint32_t)(big ? c->c2bytes_waves : c->cbytes_waves);
         const uint32_t chains = lanes * waves;
-        const size_t chain_b = big ? SnkBT<2048>::CHAIN_B : SnkBT<1024>::CHAIN_B;
-        const size_t lds = (size_t)SnkBT<1024>::LUT_B + (size_t)chains * chain_b;
+        const size_t chain_b = big ? SnkBT<2048, false>::CHAIN_B : SnkBT<1024, false>::CHAIN_B;
+        const size_t lds = (size_t)SnkBT<1024, false>::LUT_B + (size_t)chains * chain_b;
         const void *kern = big ? (const void *)snk_bytes_compact2k_kernel : (const void *)snk_bytes_compact_kernel;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "%u compact byte chains exceed the 160 KiB LDS (max %d)", chains, big ? 35 : 70);
@@ -187,7 +191,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     } else if (n_bytes) {
         const uint32_t lanes = (uint32_t)c->bytes_lanes, waves = (uint32_t)c->bytes_waves;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)chains * SnkBT<0>::CHAIN_B;
+        const size_t lds = (size_t)chains * SnkBT<0, false>::CHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "bytes_lanes*bytes_waves = %u chains exceed the 160 KiB LDS (max 18)", chains);
         HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_kernel,
@@ -197,7 +201,33 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                            T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
-    if (n_gen) {
+    if (n_gen && !c->bytes_legacy) {
+        // one-shot inputs (n <= 64 KiB): the tight-loop kernel in one-shot mode
+        const bool cmp = c->oneshot_compact_ok;
+        const uint32_t lanes = (uint32_t)(cmp ? c->cos_lanes : c->os_lanes);
+        const uint32_t waves = (uint32_t)(cmp ? c->cos_waves : c->os_waves);
+        const uint32_t chains = lanes * waves;
+        const size_t lds = cmp ? (size_t)SnkBT<1024, true>::LUT_B + (size_t)chains * SnkBT<1024, true>::CHAIN_B
+                               : (size_t)chains * SnkBT<0, true>::CHAIN_B;
+        const void *kern = cmp ? (const void *)snk_oneshot_compact_kernel : (const void *)snk_oneshot_kernel;
+        if (lds > 160 * 1024)
+            return fail(c, SNK_E_ARG, "%u one-shot chains exceed the 160 KiB LDS (max %d)", chains, cmp ? 67 : 9);
+        HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (cmp) {
+            hipFuncAttributes fa;
+            HIPCHK(c, hipFuncGetAttributes(&fa, kern));
+            if (fa.sharedSizeBytes != 0)
+                return fail(c, SNK_E_STATE, "compact one-shot kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+        }
+        const uint32_t grid = (uint32_t)((n_gen + chains - 1) / chains);
+        if (cmp)
+            hipLaunchKernelGGL(snk_oneshot_compact_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs + n_fast + n_bytes, (uint32_t)n_gen, lanes, d_out, c->d_status);
+        else
+            hipLaunchKernelGGL(snk_oneshot_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs + n_fast + n_bytes, (uint32_t)n_gen, lanes, d_out, c->d_status);
+        HIPCHK(c, hipGetLastError());
+    } else if (n_gen) {
         const uint32_t chains = (uint32_t)c->gen_chains;
         const size_t lds = (size_t)chains * 16384;
         HIPCHK(c, hipFuncSetAttribute((const void *)snk_generic_kernel,
@@ -318,7 +348,8 @@ int snk_ctx_create(int device, snk_ctx **out)
             return SNK_E_STATE;
         }
         CRCHK(hipMalloc((void **)&c->d_lut_h2c, 4096 * sizeof(uint16_t)));
-        CRCHK(hipMalloc((void **)&c->d_hashset, 128 * sizeof(uint32_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_h2c4, 8192 * sizeof(uint16_t)));
+        CRCHK(hipMalloc((void **)&c->d_hashset, (128 + 256) * sizeof(uint32_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_slot, 1024 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_hash, 1024 * sizeof(uint32_t)));
         CRCHK(hipMemcpy(c->d_lut_slot, slot.data(), 2048, hipMemcpyHostToDevice));
@@ -335,7 +366,7 @@ void snk_ctx_destroy(snk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_sequences(c);
-    dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_hashset); dfree(c->d_status);
+    dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_lut_h2c4); dfree(c->d_hashset); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -368,6 +399,9 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "cbytes_waves") {
         if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "cbytes_waves must be 1..16");
         c->cbytes_waves = (int)value;
+    } else if (k == "os_lanes" || k == "os_waves" || k == "cos_lanes" || k == "cos_waves") {
+        if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "%s must be 1..64", key);
+        (k == "os_lanes" ? c->os_lanes : k == "os_waves" ? c->os_waves : k == "cos_lanes" ? c->cos_lanes : c->cos_waves) = (int)value;
     } else if (k == "c2bytes_lanes") {
         if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "c2bytes_lanes must be 1..64");
         c->c2bytes_lanes = (int)value;
@@ -490,6 +524,36 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
                 HIPCHK(c, hipMemcpy(c->d_lut_h2c, h2c.data(), 8192, hipMemcpyHostToDevice));
                 c->compact_ok = true;
                 c->compact_cap = cnt <= 1024 ? 1024 : 2048;
+            }
+        }
+    }
+
+    // ---- the same for the one-shot hash (sequences that can take part in a pair of <= 64 KiB) ---
+    c->oneshot_compact_ok = false; c->n_hashes4 = 0;
+    if (c->bytes_compact_opt != 0 && !c->bytes_legacy) {
+        uint32_t *d_set4 = c->d_hashset + 128;
+        HIPCHK(c, hipMemsetAsync(d_set4, 0, 256 * sizeof(uint32_t), c->stream));
+        bool any = false;
+        for (size_t g = 0; g < n; ++g) {
+            if (lens[g] > SNK_BLOCK || lens[g] < 4) continue;
+            any = true;
+            uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 256);
+            hipLaunchKernelGGL(snk_hashset4_kernel, dim3(grid), dim3(256), 0, c->stream,
+                               c->d_bytes + boff[g], (uint64_t)lens[g], d_set4);
+        }
+        HIPCHK(c, hipGetLastError());
+        if (any) {
+            uint32_t set[256];
+            HIPCHK(c, hipMemcpyAsync(set, d_set4, sizeof set, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<uint16_t> h2c(8192, 0xFFFF);
+            int cnt = 0;
+            for (uint32_t hsh = 0; hsh < 8192; ++hsh)
+                if (set[hsh >> 5] >> (hsh & 31u) & 1u) { if (cnt < 1024) h2c[hsh] = (uint16_t)cnt; cnt++; }
+            c->n_hashes4 = cnt;
+            if (cnt <= 1024) {
+                HIPCHK(c, hipMemcpy(c->d_lut_h2c4, h2c.data(), 16384, hipMemcpyHostToDevice));
+                c->oneshot_compact_ok = true;
             }
         }
     }

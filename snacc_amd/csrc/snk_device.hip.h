@@ -54,7 +54,8 @@ struct SnkTables {
     uint32_t       *snap_fast;        // [n][896] slot indexed tables (ACGT sequences), absolute positions
     uint32_t       *snap_gen;         // [n][4096] hash indexed tables
     const uint16_t *lut_slot;         // [1024]  5-mer code -> table slot (0..893); colliding 5-mers share one
-    const uint16_t *lut_h2c;          // [4096]  compact byte kernel: hash -> slot 0..1023, 0xFFFF = not in the resident set
+    const uint16_t *lut_h2c;          // [4096]  compact byte kernel: hash -> slot 0..CAP-1, 0xFFFF = not in the resident set
+    const uint16_t *lut_h2c4;         // [8192]  the same for the one-shot hash of 4 bytes
     const uint8_t  *zero_pad;         // >= 2*SNK_PAD zero bytes
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };
@@ -828,20 +829,25 @@ __global__ void snk_generic_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_j
 // allows 8).  The slot is liblz4's 12-bit hash of 5 bytes, computed arithmetically.
 // Two table geometries (template parameter COMPACT):
 //   full    : slot = hash (4096 slots + 1 dummy), 8712 B per chain -> 18 chains per CU.
+// ONESHOT = liblz4's one-shot mode for inputs <= 64 KiB (a single independent block): the slot is
+// the 13-bit hash of 4 bytes and there is no distance limit -- with one block every entry is
+// "current", so the same table logic applies unchanged.
 //   compact : when the 5-byte hashes that occur in ANY resident sequence number <= 1024 (upper-case
 //             ACGT with N runs and a few IUPAC codes: typically 900-1000) or <= 2048 (soft-masked
 //             genomes), a shared LUT renames them to 0..CAP-1 (exact: it is a renaming).  Only the <= 4 five-byte strings that span the
 //             x/y seam of a pair can hash outside that set; they get the chain-private slots
 //             CAP..CAP+3.  2196 / 4380 B per chain (+ 8 KiB LUT per workgroup) -> 70 / 35 chains per CU.
-template <int CAP> struct SnkBT {                                 // CAP: 0 = full table, 1024 / 2048 = compact capacity
+template <int CAP, bool ONESHOT> struct SnkBT {                   // CAP: 0 = full table, 1024 / 2048 = compact capacity
     static constexpr bool     COMPACT = CAP != 0;
-    static constexpr uint32_t SEAM0   = (uint32_t)CAP;                  // first of the 4 seam-private slots
-    static constexpr uint32_t SLOTS   = COMPACT ? (uint32_t)CAP + 4u : 4096u;   // real slots
+    static constexpr uint32_t HASHES  = ONESHOT ? 8192u : 4096u;        // liblz4: 13-bit hash of 4 bytes / 12-bit of 5
+    static constexpr uint32_t SEAM0   = (uint32_t)CAP;                  // first of the seam-private slots
+    static constexpr uint32_t SLOTS   = COMPACT ? (uint32_t)CAP + 4u : HASHES;   // real slots
     static constexpr uint32_t DUMMY   = SLOTS;                          // absorbs the put of "nothing owed"
     static constexpr uint32_t TBL_B   = ((SLOTS + 1u + 3u) / 4u) * 8u;  // u16 entries, rounded to 8 bytes
     static constexpr uint32_t BMWORDS = (SLOTS + 1u + 31u) / 32u;
-    static constexpr uint32_t CHAIN_B = TBL_B + BMWORDS * 4u;           // 2196 (1024) / 4380 (2048) / 8716 (full)
-    static constexpr uint32_t LUT_B   = COMPACT ? 8192u : 0u;           // hash -> slot LUT at LDS offset 0
+    static constexpr uint32_t CHAIN_B = TBL_B + BMWORDS * 4u;           // 2196 (1024) / 4372 (2048) / 8716 (4096) / 17420 (8192)
+    static constexpr uint32_t LUT_B   = COMPACT ? HASHES * 2u : 0u;     // hash -> slot LUT at LDS offset 0
+    static constexpr uint32_t KBYTES  = ONESHOT ? 4u : 5u;              // bytes hashed per position
 };
 #define SNK_BC_NOSLOT   0xFFFFu
 
@@ -889,8 +895,15 @@ __device__ __forceinline__ SnkW12 snk_bfetch12(const SnkByteSrc &s, uint32_t p)
     SnkW12 r; r.a = vp->a; r.b = vp->b; r.c = vp->c;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(straddle) != 0ull, 0)) {
         if (straddle) {
-            const uint64_t lo = snk_bld8(s, (uint32_t)q0), hi = snk_bld8(s, (uint32_t)q0 + 8u);
-            r.a = (uint32_t)lo; r.b = (uint32_t)(lo >> 32); r.c = (uint32_t)hi;
+            // byte by byte: the window may start before position 0 (candidate < 4 with a prefix
+            // shorter than 12 bytes); those bytes are never used (catch-up is capped by cand)
+            uint32_t v[3] = { 0u, 0u, 0u };
+            for (int32_t k = 0; k < 12; ++k) {
+                const int32_t pos = q0 + k;
+                const uint32_t byte = pos < 0 ? 0u : snk_bbyte(s, (uint32_t)pos);
+                v[k >> 2] |= byte << (8 * (k & 3));
+            }
+            r.a = v[0]; r.b = v[1]; r.c = v[2];
         }
     }
     return r;
@@ -931,6 +944,8 @@ struct SnkByteLane {
 // and the two table slots (5 bytes at cur and at cur-2).
 struct SnkBProbeData { SnkW12 w; uint32_t s1, s2; };
 
+__device__ __forceinline__ uint32_t snk_hash4_u32(uint32_t v) { return (v * 2654435761u) >> 19; }
+
 // hash -> table slot (compact: through the LUT at LDS address 0; the kernel has no static LDS)
 template <bool COMPACT>
 __device__ __forceinline__ uint32_t snk_bslot(uint32_t h)
@@ -940,7 +955,7 @@ __device__ __forceinline__ uint32_t snk_bslot(uint32_t h)
     return lut[h];
 }
 
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t o)
 {
     const bool hi = (o & 4u) != 0u;
@@ -951,32 +966,38 @@ __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t
     d.w.b = __builtin_amdgcn_alignbit(a2, a1, sh);       // bytes cur   .. cur+3
     d.w.c = __builtin_amdgcn_alignbit(a3, a2, sh);       // bytes cur+4 .. cur+7
     // 5 bytes at cur-2 = window bytes 2..6 ; 5 bytes at cur = window bytes 4..8
-    d.s2 = snk_bslot<(CAP != 0)>(snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24)));
-    d.s1 = snk_bslot<(CAP != 0)>(snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8)));
+    if (ONESHOT) {      // 4 bytes at cur-2 = window bytes 2..5 ; 4 bytes at cur = window bytes 4..7
+        d.s2 = snk_bslot<(CAP != 0)>(snk_hash4_u32(__builtin_amdgcn_alignbit(d.w.b, d.w.a, 16)));
+        d.s1 = snk_bslot<(CAP != 0)>(snk_hash4_u32(d.w.b));
+    } else {
+        d.s2 = snk_bslot<(CAP != 0)>(snk_hash5_parts((d.w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(d.w.b, d.w.a, 24)));
+        d.s1 = snk_bslot<(CAP != 0)>(snk_hash5_parts(d.w.b << 24, __builtin_amdgcn_alignbit(d.w.c, d.w.b, 8)));
+    }
     return d;
 }
 
 // Slot of the 5 bytes at stream position p, for the slow paths (direct loads, seam aware).  In compact
 // mode a hash outside the resident set can only belong to a string spanning the seam (p in
 // [lx-4, lx-1]); equal seam hashes share one private slot, as they would share liblz4's.
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ uint32_t snk_bslot_slow(const SnkByteSrc &s, uint32_t p)
 {
     const uint64_t w0 = snk_bld8(s, p);
-    const uint32_t h = snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
+    const uint32_t h = ONESHOT ? snk_hash4_u32((uint32_t)w0) : snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
     if (CAP == 0) return h;
     const uint32_t id = snk_bslot<true>(h);
     if (__builtin_expect(id != SNK_BC_NOSLOT, 1)) return id;
-    const int32_t j0 = (int32_t)s.lx - 4;                       // first seam-spanning position (may be < 0)
+    const int32_t j0 = (int32_t)s.lx - (int32_t)(SnkBT<CAP, ONESHOT>::KBYTES - 1u);   // first seam-spanning position
     int32_t q = j0 < 0 ? 0 : j0;
     for (; q < (int32_t)p; ++q) {
         const uint64_t wq = snk_bld8(s, (uint32_t)q);
-        if (snk_hash5_parts((uint32_t)wq << 24, (uint32_t)(wq >> 8)) == h) break;
+        const uint32_t hq = ONESHOT ? snk_hash4_u32((uint32_t)wq) : snk_hash5_parts((uint32_t)wq << 24, (uint32_t)(wq >> 8));
+        if (hq == h) break;
     }
-    return SnkBT<CAP>::SEAM0 + (uint32_t)(q - j0);
+    return SnkBT<CAP, ONESHOT>::SEAM0 + (uint32_t)(q - j0);
 }
 
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                      uint32_t *out, uint32_t *status)
 {
@@ -996,7 +1017,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         if (L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
             // prefix snapshot, always in liblz4's hash-indexed form (absolute positions, 0 = too far)
             uint32_t *dst = T.snap_gen + (size_t)L.xi * 4096u;
-            for (uint32_t h = 0; h < 4096u; ++h) {
+            for (uint32_t h = 0; h < 4096u; ++h) {        // (never taken in one-shot mode: no snapshots)
                 const uint32_t t = snk_bslot<(CAP != 0)>(h);
                 uint32_t v = 0u;
                 if (CAP == 0 || t != SNK_BC_NOSLOT) {
@@ -1012,7 +1033,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.iend = L.pos + L.blen;
         if (L.blen < 13u) { L.total += 4u + L.blen; L.pos = L.iend; continue; }
         if (!L.first) {
-            for (uint32_t wi = 0; wi < (SnkBT<CAP>::SLOTS + 31u) / 32u; ++wi) {
+            for (uint32_t wi = 0; wi < (SnkBT<CAP, ONESHOT>::SLOTS + 31u) / 32u; ++wi) {
                 uint32_t z = ~bm[wi];
                 while (z) {
                     const uint32_t b = (uint32_t)__builtin_ctz(z);
@@ -1026,7 +1047,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.base = L.pos;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         {
-            const uint32_t s0 = snk_bslot_slow<CAP>(L.s, L.pos);
+            const uint32_t s0 = snk_bslot_slow<CAP, ONESHOT>(L.s, L.pos);
             tbl[s0] = 0;
             atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
         }
@@ -1067,11 +1088,11 @@ __device__ __forceinline__ void snk_bytes_match_slow(SnkByteLane &L, uint32_t cu
 }
 
 // table probe shared by the slow and the tight paths: returns candidate + validity, performs the puts
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *tbl, uint32_t *bm, uint32_t cur,
                                                 uint32_t s1, uint32_t s2, uint32_t &cand, bool &valid)
 {
-    s2 = L.pending ? s2 : SnkBT<CAP>::DUMMY;
+    s2 = L.pending ? s2 : SnkBT<CAP, ONESHOT>::DUMMY;
     const uint32_t e = tbl[s1];
     const uint32_t bw = bm[s1 >> 5];
     const uint32_t c = cur - L.base;
@@ -1090,18 +1111,18 @@ __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *
 }
 
 // One fully general probe with direct loads (stream start, seam, after long jumps).
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                     uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur, next = cur + L.step;
-    if (next > L.mfl1) return snk_bytes_block_step<CAP>(L, T, tbl, bm, out, status);
+    if (next > L.mfl1) return snk_bytes_block_step<CAP, ONESHOT>(L, T, tbl, bm, out, status);
     const uint64_t wc = snk_bld8(L.s, cur);
-    const uint32_t s1 = snk_bslot_slow<CAP>(L.s, cur);
+    const uint32_t s1 = snk_bslot_slow<CAP, ONESHOT>(L.s, cur);
     // the put of cur-2 is owed only after a match, which ends at least 5 positions into the block
-    const uint32_t s2 = L.pending ? snk_bslot_slow<CAP>(L.s, cur - 2u) : SnkBT<CAP>::DUMMY;
+    const uint32_t s2 = L.pending ? snk_bslot_slow<CAP, ONESHOT>(L.s, cur - 2u) : SnkBT<CAP, ONESHOT>::DUMMY;
     uint32_t cand; bool valid;
-    snk_bytes_table<CAP>(L, tbl, bm, cur, s1, s2, cand, valid);
+    snk_bytes_table<CAP, ONESHOT>(L, tbl, bm, cur, s1, s2, cand, valid);
     const uint32_t s3 = L.nb >> 6;
     const uint64_t wd = snk_bld8(L.s, cand);
     if (valid && (uint32_t)wc == (uint32_t)wd) {
@@ -1118,7 +1139,7 @@ __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTab
 }
 
 // Tight loop.  Invariant at the head: (nx0, nx1) hold the bytes [rb+24, rb+32).
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                uint32_t *out, uint32_t *status)
 {
@@ -1132,14 +1153,14 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             o = cur - 4u - w.rb;
             const bool pre = (next > L.mfl1) | (o > 7u) | (cur > w.lim);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
-            if (pre && snk_bytes_iter_slow<CAP>(L, T, tbl, bm, out, status)) return;
+            if (pre && snk_bytes_iter_slow<CAP, ONESHOT>(L, T, tbl, bm, out, status)) return;
         }
-        SnkBProbeData d = snk_bextract<CAP>(w, o);
+        SnkBProbeData d = snk_bextract<CAP, ONESHOT>(w, o);
         const uint32_t olim6 = L.olimit - 6u;
 
         for (;;) {
             uint32_t cand; bool valid;
-            snk_bytes_table<CAP>(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
+            snk_bytes_table<CAP, ONESHOT>(L, tbl, bm, cur, d.s1, d.s2, cand, valid);
 
             __builtin_amdgcn_sched_barrier(0);
             snk_g8 *nxp = arena + (size_t)(w.soff + (w.rb + 24u - w.org));
@@ -1169,7 +1190,7 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
             const uint32_t r3n = sl ? w.r5 : w.r3, r4n = sl ? w.nx0 : w.r4, r5n = sl ? w.nx1 : w.r5;
             no -= sl ? 8u : 0u;
             w.r0 = r0n; w.r1 = r1n; w.r2 = r2n; w.r3 = r3n; w.r4 = r4n; w.r5 = r5n; w.rb += sl ? 8u : 0u;
-            const SnkBProbeData nd = snk_bextract<CAP>(w, no & 7u);
+            const SnkBProbeData nd = snk_bextract<CAP, ONESHOT>(w, no & 7u);
             if (CAP != 0) __builtin_amdgcn_sched_barrier(0);   // keep the LUT reads in front of the bookkeeping
 
             // ---- bookkeeping of this probe ----
@@ -1201,11 +1222,11 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
 }
 
 // grid: one workgroup per `lanes*waves` jobs; dynamic LDS = LUT_B + CHAIN_B per chain.
-template <int CAP>
+template <int CAP, bool ONESHOT>
 __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
                                                       uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    typedef SnkBT<CAP> G;
+    typedef SnkBT<CAP, ONESHOT> G;
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
@@ -1216,8 +1237,9 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     uint8_t *mine = snk_lds8 + G::LUT_B + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * G::CHAIN_B;
 
     if (CAP != 0) {
-        for (uint32_t t = tid; t < 2048u; t += blockDim.x)
-            ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_h2c)[t];
+        const uint32_t *lsrc = (const uint32_t *)(ONESHOT ? T.lut_h2c4 : T.lut_h2c);
+        for (uint32_t t = tid; t < G::LUT_B / 4u; t += blockDim.x)
+            ((uint32_t *)snk_lds8)[t] = lsrc[t];
         __syncthreads();
     }
     SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
@@ -1230,7 +1252,7 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
         if (!a) continue;
         uint8_t *dst = snk_lds8 + G::LUT_B + (size_t)(wave * lanes + l) * G::CHAIN_B;
         const uint32_t spos = T.snap_pos[xi];
-        const bool use = (snp == 0) && (spos != 0u);
+        const bool use = !ONESHOT && (snp == 0) && (spos != 0u);
         const uint32_t *src = T.snap_gen + (size_t)xi * 4096u;
         if (CAP == 0) {
             for (uint32_t t = lane; t < G::TBL_B / 4u; t += 64u) {
@@ -1273,8 +1295,9 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.n = lx + ly;
     L.spos = T.snap_pos[job.xi];
     L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;
-    if (job.snap == 0 && L.spos != 0u) { L.pos = L.spos; L.total = T.snap_out[job.xi]; }
-    else                               { L.pos = 0u;     L.total = T.header_bytes; }
+    if (!ONESHOT && job.snap == 0 && L.spos != 0u) { L.pos = L.spos; L.total = T.snap_out[job.xi]; }
+    else                                           { L.pos = 0u;     L.total = T.header_bytes; }
+    if (ONESHOT) L.snap = 0;
     L.blocks_left = (L.n >> 16) + 4u;
     L.iend = 0; L.blen = 0; L.first = true; L.in_block = false;
     L.cur = 0; L.step = 1; L.nb = 64; L.anchor = 0; L.op = 0;
@@ -1282,25 +1305,38 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
     L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
-    snk_bytes_loop<CAP>(L, T, tbl, bm, out, status);
+    snk_bytes_loop<CAP, ONESHOT>(L, T, tbl, bm, out, status);
 }
 
 __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                  uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_bytes_kernel_body<0>(T, jobs, n_jobs, lanes, out, status);
+    snk_bytes_kernel_body<0, false>(T, jobs, n_jobs, lanes, out, status);
 }
 
 __global__ void snk_bytes_compact_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                          uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_bytes_kernel_body<1024>(T, jobs, n_jobs, lanes, out, status);
+    snk_bytes_kernel_body<1024, false>(T, jobs, n_jobs, lanes, out, status);
 }
 
 __global__ void snk_bytes_compact2k_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                            uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_bytes_kernel_body<2048>(T, jobs, n_jobs, lanes, out, status);
+    snk_bytes_kernel_body<2048, false>(T, jobs, n_jobs, lanes, out, status);
+}
+
+// one-shot mode (n <= 64 KiB): full 8192-slot table, and the compact form
+__global__ void snk_oneshot_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                   uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<0, true>(T, jobs, n_jobs, lanes, out, status);
+}
+
+__global__ void snk_oneshot_compact_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                           uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<1024, true>(T, jobs, n_jobs, lanes, out, status);
 }
 
 // =========================================================================
@@ -1357,6 +1393,28 @@ __global__ void snk_hashset_kernel(const uint8_t *bytes, uint64_t n, uint32_t *s
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < 128u; t += blockDim.x)
+        if (local[t]) atomicOr(&set[t], local[t]);
+}
+
+// Same for the one-shot hash (13 bits of 4 bytes, positions p <= n-4); `set` has 256 words.
+__global__ void snk_hashset4_kernel(const uint8_t *bytes, uint64_t n, uint32_t *set)
+{
+    __shared__ uint32_t local[256];
+    for (uint32_t t = threadIdx.x; t < 256u; t += blockDim.x) local[t] = 0u;
+    __syncthreads();
+    if (n >= 4) {
+        const uint64_t last = n - 4;
+        uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (; p <= last; p += stride) {
+            uint32_t v = 0;
+            for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)bytes[p + b] << (8u * b);
+            const uint32_t h = (v * 2654435761u) >> 19;
+            atomicOr(&local[h >> 5], 1u << (h & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 256u; t += blockDim.x)
         if (local[t]) atomicOr(&set[t], local[t]);
 }
 

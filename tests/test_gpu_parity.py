@@ -135,6 +135,24 @@ def test_compact_2048_soft_masked_genomes(hip, oracle_mod):
     assert np.array_equal(p, np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32))
 
 
+def test_oneshot_small_genomes(hip, oracle_mod):
+    """Pairs of <= 64 KiB (viral / mitochondrial sizes) use liblz4's one-shot mode (13-bit hash of 4
+    bytes): tight-loop kernel with compact table, with the full 8192-slot table, and the legacy
+    kernel must all agree with the oracle.  Includes sums of exactly 65536 and seam strings with N."""
+    o = oracle_mod
+    rng = np.random.default_rng(4)
+    anc = o.lcg_genome(50, 10700)
+    seqs = [bytes(anc)] + [bytes(o.lcg_mutant(anc, 60 + i)) for i in range(5)]
+    seqs += [bytes(o.lcg_genome(70, 16569)), bytes(o.lcg_genome(71, 32768)), bytes(o.lcg_genome(72, 32768)),
+             bytes(o.lcg_genome(73, 29000)) + b"NNN", b"NN" + bytes(o.lcg_genome(74, 5000)), b"ACGT" * 3, b"A" * 20000,
+             bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), 9000)), b"", b"ACGTACGTACGTA"]
+    for opts in ({}, {"bytes_compact": 0}, {"bytes_legacy": 1}, {"cos_lanes": 5, "cos_waves": 3}):
+        _check_all(hip, oracle_mod, seqs, **opts)
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert ctx.num_packed >= 8
+
+
 def test_compact_falls_back_when_too_many_hashes(hip, oracle_mod):
     rng = np.random.default_rng(3)
     seqs = [oracle_mod.lcg_genome(1, 100000), rng.integers(0, 256, 100000, dtype=np.uint8)]
