@@ -141,7 +141,7 @@ int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
 
 // Launch the kernels over a job list laid out as [2-bit jobs | linked byte jobs | one-shot jobs].
 int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_fast, size_t n_bytes, size_t n_gen,
-                uint32_t *d_out)
+                uint32_t *d_out, bool singles = false)
 {
     SnkTables T = make_tables(c);
     if (n_fast) {
@@ -150,17 +150,21 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", chains);
-        HIPCHK(c, hipFuncSetAttribute((const void *)snk_fast_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void *fk = singles ? (const void *)snk_fast_singles_kernel : (const void *)snk_fast_kernel;
+        HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {   // the kernel addresses its slot LUT at LDS offset 0: that holds only without static LDS
             hipFuncAttributes fa;
-            HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)snk_fast_kernel));
+            HIPCHK(c, hipFuncGetAttributes(&fa, fk));
             if (fa.sharedSizeBytes != 0)
                 return fail(c, SNK_E_STATE, "snk_fast_kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
         }
         const uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
-        hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                           T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+        if (singles)
+            hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+        else
+            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
     if (n_bytes && c->compact_ok) {
@@ -600,7 +604,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     int rc = ensure_scratch(c, n, 0);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), n * sizeof(SnkJob), hipMemcpyHostToDevice, c->stream));
-    rc = launch_jobs(c, c->stream, c->d_jobs, nf, nb, ng, c->d_single);
+    rc = launch_jobs(c, c->stream, c->d_jobs, nf, nb, ng, c->d_single, true);
     if (rc) return rc;
     if (!conv.empty()) {
         uint32_t *d_ids = nullptr;
