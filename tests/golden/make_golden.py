@@ -10,8 +10,8 @@ What is recorded (data only -- inputs and expected outputs):
 2. Outputs of the REFERENCE's own Python (``/root/reference/snacc/pairwise_ncd.py`` and
    ``cli.py``, imported unmodified) for its fixture ``test_dataset/sample.fa`` and for small
    synthetic FASTA sets: ``extract_sequences``, ``compressed_size`` (all codecs),
-   ``compute_distance`` known answers and the CSV matrix the CLI writes with ``-c lz4`` with
-   and without ``-r``.
+   ``compute_distance`` known answers, the CSV matrix the CLI writes with ``-c lz4`` with
+   and without ``-r``, and one run of the CLI with a stdlib codec (``-c gzip``: CSV, banners, log).
 
 The reference imports two third-party modules that are absent from this image and cannot be
 fetched (``lz4framed``, ``Bio``).  To run its glue code here they are replaced IN MEMORY by
@@ -240,6 +240,28 @@ def main():
             cli_out[set_name] = entry
     gold["cli_lz4"] = {"sets": {k: {"newline": v["newline"], "files": v["files"]} for k, v in CLI_SETS.items()},
                        "outputs": cli_out}
+
+    # the reference CLI with a stdlib codec (CPU pass-through flow) on the small set, incl. the run log
+    with tempfile.TemporaryDirectory() as td:
+        d = Path(td) / "fa"
+        d.mkdir()
+        spec = CLI_SETS["acgt_small"]
+        for fname, recs in spec["files"].items():
+            write_fasta(d / fname, [(t, make_seq(k, s, n)) for (t, k, s, n) in recs], newline=spec["newline"])
+        out = Path(td) / "gz.csv"
+        cwd = os.getcwd()
+        os.chdir(td)
+        try:
+            res = CliRunner().invoke(rcli.cli, [str(d), "-o", str(out), "-c", "gzip", "-n", "2", "--no-show-progress"])
+        finally:
+            os.chdir(cwd)
+        assert res.exit_code == 0, res.output
+        log_lines = (Path(td) / "gz.md").read_text().splitlines()
+        gold["cli_gzip"] = {"set": "acgt_small", "csv": out.read_text().replace(str(d) + "/", "{DIR}/"),
+                            "stdout": res.output,
+                            # run-log lines that do not depend on time, versions or the output path
+                            "log_fixed_lines": [ln.replace(str(d) + "/", "{DIR}/") for ln in log_lines
+                                                if not ln.startswith(("* Analysis", "* Output", "* Python", "* snacc", "* py-lz4framed"))]}
 
     out_path = Path(__file__).with_name("golden.json")
     out_path.write_text(json.dumps(gold, indent=1, sort_keys=True) + "\n")

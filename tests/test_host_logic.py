@@ -145,3 +145,48 @@ def test_direct_csv_writer_equals_pandas(tmp_path):
     write_matrix_csv(files, m, a)
     write_matrix_csv_pandas(files, m, b)
     assert a.read_bytes() == b.read_bytes()
+
+
+def test_cli_gzip_flow_matches_reference_cli(golden, oracle_mod, tmp_path, monkeypatch):
+    """`snacc <dir> -c gzip` (the CPU pass-through flow the reference runs, ref:snacc/cli.py:104-160):
+    CSV bytes, phase banners and the fixed lines of the Markdown run log equal the reference CLI's."""
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    g = golden["cli_gzip"]
+    spec = golden["cli_lz4"]["sets"][g["set"]]
+    d = materialise_cli_set(oracle_mod, spec, tmp_path / "fa")
+    out = tmp_path / "gz.csv"
+    monkeypatch.chdir(tmp_path)
+    res = CliRunner().invoke(cli, [str(d), "-o", str(out), "-c", "gzip", "-n", "2", "--no-show-progress"])
+    assert res.exit_code == 0, res.output
+    assert res.output == g["stdout"]
+    assert out.read_text() == g["csv"].replace("{DIR}", str(d))
+    log = (tmp_path / "gz.md").read_text().splitlines()
+    fixed = [ln for ln in log if not ln.startswith(("* Analysis", "* Output", "* Python", "* snacc", "* py-lz4framed"))]
+    assert fixed == [ln.replace("{DIR}", str(d)) for ln in g["log_fixed_lines"]]
+    assert any(ln.startswith("* py-lz4framed: n/a (snacc_amd") for ln in log)
+
+
+def test_cli_rejects_save_compression_with_lz4(tmp_path):
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    f = tmp_path / "a.fa"
+    f.write_text(">a\nACGT\n")
+    blobs = tmp_path / "blobs"
+    blobs.mkdir()
+    res = CliRunner().invoke(cli, [str(f), "-o", str(tmp_path / "o.csv"), "-c", "lz4", "-s", str(blobs), "--no-log"])
+    assert res.exit_code != 0 and "save-compression" in res.output
+
+
+def test_cli_deprecated_flags_warn_and_work(tmp_path, monkeypatch):
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "a.fa").write_text(">a\nACGTACGTAC\n")
+    (d / "b.fa").write_text(">b\nACGTACGTTT\n")
+    monkeypatch.chdir(tmp_path)
+    res = CliRunner().invoke(cli, ["-d", str(d), "-f", str(d / "a.fa"), "-o", "o.csv", "-c", "zlib", "--no-show-progress", "--no-log"])
+    assert res.exit_code == 0, res.output
+    assert "deprecated" in res.output
+    assert len((tmp_path / "o.csv").read_text().splitlines()) == 3
