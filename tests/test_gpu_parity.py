@@ -374,3 +374,19 @@ def test_edge_cases_single_sequence_and_duplicates(hip, oracle_mod):
         assert (p == p[0, 0]).all() and int(p[0, 0]) == o.lz4f_size_pair(g, g)
         ctx.upload([])
         assert ctx.singles().size == 0 and ctx.pairs().size == 0
+
+
+def test_long_genomes_large_offsets(hip, oracle_mod):
+    """12.5 Mbp genomes: stream positions beyond 2^24, 380 blocks per pair, arena offsets in the
+    MB range -- on the 2-bit kernel, and with one N on the (compact) byte kernel."""
+    o = oracle_mod
+    a, b = o.lcg_genome(301, 12_500_000), o.lcg_genome(302, 12_345_678)
+    c = b.copy()
+    c[7_000_000] = ord("N")
+    seqs = [a, b, c]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert ctx.num_packed == 2
+        s, p = ctx.singles(), ctx.pairs()
+    assert s.tolist() == [o.lz4f_size(x) for x in seqs]
+    assert p.tolist() == [[o.lz4f_size_pair(x, y) for y in seqs] for x in seqs]
