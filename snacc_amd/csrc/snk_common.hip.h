@@ -1,0 +1,87 @@
+// snk_common.hip.h -- shared declarations of the gfx950 lz4-frame size kernels.
+// (kernels: snk_fast.hip.h, snk_bytes.hip.h, snk_legacy.hip.h, snk_ingest.hip.h; all included by snk_device.hip.h)
+//
+// Replaces (size only) lz4framed.compress at ref:snacc/pairwise_ncd.py:80 for the
+// N + N*N compressions issued by ref:snacc/cli.py:108-129.  Bit-exact against
+// liblz4 1.9.3 LZ4F_compressFrame(prefs=NULL); the algorithm statement is in
+// SURVEY.md 8(c-spec) and DESIGN.md.
+//
+// Execution model (CDNA4).  The LZ4 "fast" parse of one stream is a strictly serial chain (each
+// probe depends on the previous match length and on every earlier hash-table write), so
+// parallelism comes from running MANY independent chains.  One *lane* owns one chain (one ordered
+// pair or one single sequence); its hash table lives in LDS, and LDS bytes per chain is what limits
+// the chains resident per CU.  Every kernel runs the parse as ONE flat probe loop per lane (search
+// probes and post-match probes are the same code; rare events leave through wave-uniform side
+// exits) so that lanes in different phases of their parse still execute the same instructions.
+//
+//   snk_fast.hip.h    2-bit kernel: both sequences pure upper-case ACGT.  Table = 894 collision
+//                     classes of liblz4's hash (5-mer -> slot LUT) as 16-bit block offsets + a
+//                     "written this block" bitmap: 1904 B per chain, 84 chains per CU.
+//   snk_bytes.hip.h   byte kernels for any alphabet: full 4096-slot table (18 chains per CU) or,
+//                     when the resident sequences use <= 1024 / 2048 distinct 5-byte hashes, a
+//                     renamed compact table (70 / 35 chains per CU); one-shot mode for inputs
+//                     <= 64 KiB (13-bit hash of 4 bytes, single block).
+//   snk_legacy.hip.h  the first byte kernel (nested loops, liblz4's own u32 / u16 tables), kept as
+//                     an independent second implementation for cross-checks.
+//   snk_ingest.hip.h  classify / 2-bit pack / hash sets / snapshot conversion.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SNK_BLOCK       65536u
+#define SNK_MAXDIST     65535u
+#define SNK_PAD         64        // zero bytes before and after every sequence buffer
+
+// status bits written by kernels
+#define SNK_ST_ITERCAP  1u
+
+struct SnkJob {
+    int32_t  xi;        // prefix sequence
+    int32_t  yi;        // suffix sequence, -1 = single (stream is x alone)
+    uint32_t out_idx;   // where the frame size goes
+    int32_t  snap;      // 1 = dump the prefix snapshot of xi when its boundary is reached
+};
+
+struct SnkTables {
+    // per-sequence, all device pointers
+    const uint8_t  *const *bytes;     // ASCII, padded (per-sequence pointers, legacy byte kernel)
+    const uint8_t  *bytes_arena;      // the same ASCII data as one allocation < 4 GiB; starts with SNK_PAD zero bytes
+    const uint32_t *bytes_off;        // byte offset of each sequence in the ASCII arena
+    const uint8_t  *packed_arena;     // 2-bit packed sequences, one allocation < 4 GiB; starts with 4*SNK_PAD zero bytes
+    const uint32_t *packed_off;       // byte offset of each packed sequence in the arena (0 = not packed)
+    const uint32_t *len;
+    const uint32_t *snap_pos;         // block-aligned prefix length covered by the snapshot (0 = none)
+    uint32_t       *snap_out;         // frame bytes (header included) after snap_pos
+    uint32_t       *snap_fast;        // [n][896] slot indexed tables (ACGT sequences), absolute positions
+    uint32_t       *snap_gen;         // [n][4096] hash indexed tables
+    const uint16_t *lut_slot;         // [1024]  5-mer code -> table slot (0..893); colliding 5-mers share one
+    const uint16_t *lut_h2c;          // [4096]  compact byte kernel: hash -> slot 0..CAP-1, 0xFFFF = not in the resident set
+    const uint16_t *lut_h2c4;         // [8192]  the same for the one-shot hash of 4 bytes
+    const uint8_t  *zero_pad;         // >= 2*SNK_PAD zero bytes
+    uint32_t        header_bytes;     // 7, or 15 with the content-size field
+};
+
+__device__ __forceinline__ uint64_t snk_ld8u(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);        // byte-aligned; gfx950 global/LDS loads allow it
+    return v;
+}
+
+__device__ __forceinline__ uint32_t snk_lit_ext(uint32_t lit)
+{
+    return lit >= 15u ? (lit - 15u) / 255u + 1u : 0u;
+}
+
+// global-memory (address space 1) pointers keep hipcc on global_load_* instead of flat_load_*
+typedef __attribute__((address_space(1))) const uint8_t snk_g8;
+struct __attribute__((packed)) SnkU64 { uint64_t v; };
+struct __attribute__((packed)) SnkU32 { uint32_t v; };
+__device__ __forceinline__ uint64_t snk_ld8g(snk_g8 *p)
+{
+    return ((__attribute__((address_space(1))) const SnkU64 *)p)->v;   // byte-aligned 8-byte load
+}
+__device__ __forceinline__ uint32_t snk_ld4g(snk_g8 *p)
+{
+    return ((__attribute__((address_space(1))) const SnkU32 *)p)->v;   // byte-aligned 4-byte load
+}

@@ -1,0 +1,99 @@
+// snk_ingest.hip.h -- ingest helpers: classify, 2-bit pack, hash sets, snapshot conversion.
+// Part of the device code of libsnacc_hip.so; see snk_common.hip.h for the execution model.
+#pragma once
+#include "snk_common.hip.h"
+
+#include "snk_fast.hip.h"     // SNK_FSLOTS
+
+// =========================================================================
+//  ingest kernels
+// =========================================================================
+
+// flags[g] bit0 is cleared when a byte outside {A,C,G,T} is seen.
+__global__ void snk_classify_kernel(const uint8_t *bytes, uint64_t n, uint32_t *flag)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < n; i += stride) {
+        uint8_t c = bytes[i];
+        bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, ~1u);
+}
+
+// 2-bit pack: code = (c >> 1) & 3  (A=0, C=1, T=2, G=3); one output byte per thread.
+__global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packed)
+{
+    uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nbytes = (n + 3) >> 2;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; o < nbytes; o += stride) {
+        uint32_t v = 0;
+        for (uint32_t b = 0; b < 4u; ++b) {
+            uint64_t i = o * 4 + b;
+            uint32_t code = i < n ? ((bytes[i] >> 1) & 3u) : 0u;
+            v |= code << (2u * b);
+        }
+        packed[o] = (uint8_t)v;
+    }
+}
+
+// Which of liblz4's 4096 hash values occur inside one sequence (5 bytes at every position p <= n-5).
+// One 4096-bit set per launch target, OR-ed into `set` (128 words).
+__global__ void snk_hashset_kernel(const uint8_t *bytes, uint64_t n, uint32_t *set)
+{
+    __shared__ uint32_t local[128];
+    for (uint32_t t = threadIdx.x; t < 128u; t += blockDim.x) local[t] = 0u;
+    __syncthreads();
+    if (n >= 5) {
+        const uint64_t last = n - 5;
+        uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (; p <= last; p += stride) {
+            uint64_t v = 0;
+            for (uint32_t b = 0; b < 5u; ++b) v |= (uint64_t)bytes[p + b] << (8u * b);
+            const uint32_t h = (uint32_t)(((v << 24) * 889523592379ull) >> 52);
+            atomicOr(&local[h >> 5], 1u << (h & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 128u; t += blockDim.x)
+        if (local[t]) atomicOr(&set[t], local[t]);
+}
+
+// Same for the one-shot hash (13 bits of 4 bytes, positions p <= n-4); `set` has 256 words.
+__global__ void snk_hashset4_kernel(const uint8_t *bytes, uint64_t n, uint32_t *set)
+{
+    __shared__ uint32_t local[256];
+    for (uint32_t t = threadIdx.x; t < 256u; t += blockDim.x) local[t] = 0u;
+    __syncthreads();
+    if (n >= 4) {
+        const uint64_t last = n - 4;
+        uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (; p <= last; p += stride) {
+            uint32_t v = 0;
+            for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)bytes[p + b] << (8u * b);
+            const uint32_t h = (v * 2654435761u) >> 19;
+            atomicOr(&local[h >> 5], 1u << (h & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 256u; t += blockDim.x)
+        if (local[t]) atomicOr(&set[t], local[t]);
+}
+
+// slot-indexed snapshot -> hash-indexed snapshot (for ACGT prefix + non-ACGT suffix pairs)
+__global__ void snk_snap_convert_kernel(const uint32_t *snap_fast, uint32_t *snap_gen,
+                                        const uint32_t *lut_hash, const uint16_t *lut_slot,
+                                        const uint32_t *seq_ids, uint32_t n_ids)
+{
+    const uint32_t g = seq_ids[blockIdx.x];
+    (void)n_ids;
+    uint32_t *dst = snap_gen + (size_t)g * 4096u;
+    const uint32_t *src = snap_fast + (size_t)g * SNK_FSLOTS;
+    for (uint32_t t = threadIdx.x; t < 4096u; t += blockDim.x) dst[t] = 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) dst[lut_hash[k]] = src[lut_slot[k]];
+}

@@ -35,7 +35,7 @@ _lib = None
 def build(force=False):
     """Compile the library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("snacc_hip.hip", "snk_device.hip.h", "snk_fasta.cpp")]
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h", ".cpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "snacc_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
