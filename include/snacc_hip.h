@@ -106,6 +106,14 @@ int snk_pairs_device(snk_ctx *ctx, int row_begin, int row_end, void *d_sizes, vo
  * Used by compressed_size((a, b), "lz4") (one pair per call in the reference). */
 int snk_pairs_list(snk_ctx *ctx, int n_pairs, const int32_t *ij, uint32_t *sizes /* host */);
 
+/* The compressed FRAMES themselves (ref:snacc/pairwise_ncd.py:82-88 writes them
+ * with -s/--save-compression).  Item t is the single sequence ij[2t] when ij[2t+1] == -1, else
+ * the concatenation seq[ij[2t]] + seq[ij[2t+1]].  `offsets` has n_items+1 entries, offsets[t+1] -
+ * offsets[t] = the frame size obtained from snk_singles / snk_pairs_list; frame t is written to
+ * out[offsets[t] ...].  Bytes equal liblz4 1.9.3 LZ4F_compressFrame(prefs = NULL).  Not available
+ * with the content_size option. */
+int snk_frames_list(snk_ctx *ctx, int n_items, const int32_t *ij, const uint64_t *offsets, uint8_t *out);
+
 /* Wait for outstanding work on the context's stream / the given stream and
  * return SNK_E_KERNEL if any launch since the last check flagged an error. */
 int snk_sync(snk_ctx *ctx, void *hip_stream);

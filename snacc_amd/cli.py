@@ -23,7 +23,7 @@ import pandas as pd
 from tqdm import tqdm
 
 from .matrix import GETSIZEOF_OVERHEAD, ncd_matrix
-from .pairwise_ncd import compressed_size, compute_distance, extract_sequences
+from .pairwise_ncd import blob_name, compressed_size, compute_distance, extract_sequences
 from .version import __version__
 
 FASTA_SUFFIXES = [".fasta", ".fna", ".fa", ".faa", ".fsa"]
@@ -81,7 +81,31 @@ def _dist_env():
     return world, rank
 
 
-def lz4_matrix(files, reverse_complement, show_progress):
+def save_lz4_blobs(ctx, files, save_directory, rows=None):
+    """-s/--save-compression with lz4: write the frame of every file and of every ordered pair,
+    named as the reference names them (ref:snacc/pairwise_ncd.py:82-88).  Frames are emitted on the
+    GPU in bounded batches."""
+    n = len(files)
+    items = [(i, -1) for i in range(n)]
+    r0, r1 = rows if rows is not None else (0, n)
+    items += [(i, j) for i in range(r0, r1) for j in range(n)]
+    budget = 256 << 20                                             # bytes of frames per batch
+    singles = ctx.singles()
+    start = 0
+    while start < len(items):
+        end, size = start, 0
+        while end < len(items) and (end == start or size < budget):
+            i, j = items[end]
+            size += int(singles[i]) + (int(singles[j]) if j >= 0 else 0)      # upper estimate
+            end += 1
+        for (i, j), blob in zip(items[start:end], ctx.frames(items[start:end])):
+            key = files[i] if j < 0 else (files[i], files[j])
+            with open(os.path.join(save_directory.absolute(), blob_name(key, ".lz4")), "wb") as f:
+                f.write(blob)
+        start = end
+
+
+def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
     """Phases A-C for ``-c lz4`` on the HIP backend.  Returns the float64 NCD matrix in `files`
     order on rank 0 (None on other ranks)."""
     from .hip_backend import HipContext
@@ -107,6 +131,8 @@ def lz4_matrix(files, reverse_complement, show_progress):
             pairs = all_pairs_hip(ctx, n).astype(np.int64) + GETSIZEOF_OVERHEAD
         else:
             pairs = ctx.pairs().astype(np.int64) + GETSIZEOF_OVERHEAD
+        if save_directory is not None and rank == 0:
+            save_lz4_blobs(ctx, files, save_directory)
     finally:
         ctx.close()
     if rank != 0:
@@ -174,10 +200,7 @@ def cli(sequences, fasta, directories, numThreads, compression, showProgress, sa
     files = discover_files(sequences, fasta, directories)
 
     if compression == "lz4":
-        if saveCompression:
-            raise click.UsageError("-s/--save-compression is not available with -c lz4 on the HIP backend "
-                                   "(sizes only; SURVEY.md 8f N4)")
-        matrix = lz4_matrix(files, reverse_complement, showProgress)
+        matrix = lz4_matrix(files, reverse_complement, showProgress, saveCompression)
     else:
         matrix = threadpool_matrix(files, compression, numThreads, saveCompression, reverse_complement,
                                    showProgress)

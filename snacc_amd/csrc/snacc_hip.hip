@@ -724,6 +724,51 @@ int snk_debug_read_stamps(unsigned long long *out8)
 }
 #endif
 
+int snk_frames_list(snk_ctx *c, int n_items, const int32_t *ij, const uint64_t *offsets, uint8_t *out)
+{
+    if (!c || n_items < 0 || (n_items && (!ij || !offsets || !out))) return fail(c, SNK_E_ARG, "bad arguments");
+    if (!c->singles_done) return fail(c, SNK_E_STATE, "snk_upload has not completed");
+    if (c->header_bytes != 7) return fail(c, SNK_E_STATE, "frame emission does not support the content_size option");
+    if (!n_items) return SNK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<SnkEmitJob> jobs((size_t)n_items);
+    for (int t = 0; t < n_items; ++t) {
+        const int i = ij[2 * t], j = ij[2 * t + 1];
+        if (i < 0 || i >= c->n || j < -1 || j >= c->n) return fail(c, SNK_E_ARG, "item %d: index out of range", t);
+        const uint64_t n = (uint64_t)c->len[i] + (j >= 0 ? c->len[j] : 0u);
+        if (n >= 0x7E000000ull) return fail(c, SNK_E_TOOBIG, "item %d too long", t);
+        if (offsets[t + 1] < offsets[t]) return fail(c, SNK_E_ARG, "offsets must be non-decreasing");
+        jobs[(size_t)t].xi = i; jobs[(size_t)t].yi = j; jobs[(size_t)t].off = offsets[t];
+    }
+    const uint64_t total = offsets[n_items];
+    SnkEmitJob *d_jobs = nullptr; uint8_t *d_frames = nullptr; uint32_t *d_sizes = nullptr;
+    auto cleanup = [&]() { dfree(d_jobs); dfree(d_frames); dfree(d_sizes); };
+#define EMCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, SNK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    EMCHK(hipMalloc((void **)&d_jobs, jobs.size() * sizeof(SnkEmitJob)));
+    EMCHK(hipMalloc((void **)&d_frames, total + 64));
+    EMCHK(hipMalloc((void **)&d_sizes, (size_t)n_items * 4));
+    EMCHK(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(SnkEmitJob), hipMemcpyHostToDevice, c->stream));
+    const uint32_t chains = 8;
+    const size_t lds = (size_t)chains * 16384;
+    EMCHK(hipFuncSetAttribute((const void *)snk_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(snk_emit_kernel, dim3((uint32_t)((n_items + chains - 1) / chains)), dim3(64), lds, c->stream,
+                       make_tables(c), d_jobs, (uint32_t)n_items, chains, d_frames, d_sizes, c->d_status);
+    EMCHK(hipGetLastError());
+    EMCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> sizes((size_t)n_items);
+    EMCHK(hipMemcpy(sizes.data(), d_sizes, sizes.size() * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < n_items; ++t)
+        if ((uint64_t)sizes[(size_t)t] != offsets[t + 1] - offsets[t]) {
+            cleanup();
+            return fail(c, SNK_E_ARG, "item %d: frame is %u bytes but the offsets reserve %llu", t, sizes[(size_t)t],
+                        (unsigned long long)(offsets[t + 1] - offsets[t]));
+        }
+    EMCHK(hipMemcpy(out, d_frames, total, hipMemcpyDeviceToHost));
+#undef EMCHK
+    cleanup();
+    return check_status(c);
+}
+
 double snk_last_pairs_ms(snk_ctx *c)
 {
     if (!c || !c->ev_valid) return -1.0;

@@ -5,3 +5,4 @@
 #include "snk_legacy.hip.h"
 #include "snk_bytes.hip.h"
 #include "snk_ingest.hip.h"
+#include "snk_emit.hip.h"

@@ -20,7 +20,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
     "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
-    "snk_pairs_device", "snk_pairs_list", "snk_sync", "snk_last_pairs_ms",
+    "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
 )
 
@@ -93,6 +93,8 @@ def load():
     L.snk_pairs_device.argtypes = [vp, i32, i32, vp, vp]
     L.snk_pairs_list.restype = i32
     L.snk_pairs_list.argtypes = [vp, i32, vp, u32p]
+    L.snk_frames_list.restype = i32
+    L.snk_frames_list.argtypes = [vp, i32, vp, vp, vp]
     L.snk_sync.restype = i32
     L.snk_sync.argtypes = [vp, vp]
     L.snk_last_pairs_ms.restype = ctypes.c_double
@@ -247,6 +249,25 @@ class HipContext:
         out = np.zeros(len(ij), dtype=np.uint32)
         self._check(self._L.snk_pairs_list(self._h, len(ij), ij.ctypes.data, out.ctypes.data), "snk_pairs_list")
         return out
+
+    def frames(self, items):
+        """Compressed LZ4 frames (bytes) of ``items``: ``(i, -1)`` = sequence i alone, ``(i, j)`` = seq_i + seq_j."""
+        ij = np.ascontiguousarray(items, dtype=np.int32).reshape(-1, 2)
+        n = len(ij)
+        if n == 0:
+            return []
+        sizes = np.zeros(n, dtype=np.uint64)
+        single = ij[:, 1] < 0
+        if single.any():
+            sizes[single] = self.singles()[ij[single, 0]]
+        if (~single).any():
+            sizes[~single] = self.pairs_list(ij[~single])
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=offsets[1:])
+        out = np.zeros(int(offsets[-1]), dtype=np.uint8)
+        self._check(self._L.snk_frames_list(self._h, n, ij.ctypes.data, offsets.ctypes.data, out.ctypes.data),
+                    "snk_frames_list")
+        return [out[int(offsets[t]):int(offsets[t + 1])].tobytes() for t in range(n)]
 
     def sync(self, stream=None):
         self._check(self._L.snk_sync(self._h, ctypes.c_void_p(stream) if stream else None), "snk_sync")

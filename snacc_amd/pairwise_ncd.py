@@ -61,15 +61,15 @@ def compressed_size(sequences, algorithm, reverse_complement=False, save_directo
     file_ext = _EXTENSION[algorithm]          # KeyError for unknown algorithms, as in the reference
 
     if algorithm == "lz4":
-        if save_directory:
-            raise NotImplementedError("lz4 on the HIP backend returns sizes only; saving the compressed "
-                                      "blob (-s with -c lz4) is not implemented (SURVEY.md 8f N4)")
         ctx = _hip_context()
         ctx.upload([bytes(p, encoding="utf-8") for p in parts])
-        if len(parts) == 2:
-            n = int(ctx.pairs_list([(0, 1)])[0])
-        else:
-            n = int(ctx.singles()[0])
+        item = (0, 1) if len(parts) == 2 else (0, -1)
+        if save_directory:
+            # the frame itself, emitted on the GPU (bytes equal liblz4's)
+            compressed_seq = ctx.frames([item])[0]
+            _save_blob(sequences, save_directory, file_ext, compressed_seq)
+            return (sequences, sys.getsizeof(compressed_seq))
+        n = int(ctx.pairs_list([item])[0]) if len(parts) == 2 else int(ctx.singles()[0])
         return (sequences, n + GETSIZEOF_OVERHEAD)
 
     sequence = bytes("".join(parts), encoding="utf-8")
@@ -82,13 +82,20 @@ def compressed_size(sequences, algorithm, reverse_complement=False, save_directo
     elif algorithm == "zlib":
         compressed_seq = zlib.compress(sequence)
     if save_directory:
-        if type(sequences) == tuple:
-            out_file = sequences[0].stem + sequences[1].name
-        else:
-            out_file = sequences.name
-        with open(os.path.join(save_directory.absolute(), out_file + file_ext), "wb") as f:
-            f.write(compressed_seq)
+        _save_blob(sequences, save_directory, file_ext, compressed_seq)
     return (sequences, sys.getsizeof(compressed_seq))
+
+
+def blob_name(sequences, file_ext):
+    """File name of a saved blob, ref:snacc/pairwise_ncd.py:83-86: ``a.stem + b.name`` for a pair."""
+    if type(sequences) == tuple:
+        return sequences[0].stem + sequences[1].name + file_ext
+    return sequences.name + file_ext
+
+
+def _save_blob(sequences, save_directory, file_ext, compressed_seq):
+    with open(os.path.join(save_directory.absolute(), blob_name(sequences, file_ext)), "wb") as f:
+        f.write(compressed_seq)
 
 
 def compute_distance(x, y, cxy, cyx):

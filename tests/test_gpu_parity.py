@@ -390,3 +390,62 @@ def test_long_genomes_large_offsets(hip, oracle_mod):
         s, p = ctx.singles(), ctx.pairs()
     assert s.tolist() == [o.lz4f_size(x) for x in seqs]
     assert p.tolist() == [[o.lz4f_size_pair(x, y) for y in seqs] for x in seqs]
+
+
+def test_emitted_frames_bytes_and_roundtrip(hip, golden, oracle_mod, tmp_path):
+    """the GPU emits the LZ4 frames themselves.  Bytes equal the liblz4 1.9.3 binary's
+    (when present), the golden frame strings, and every frame decodes back to its input."""
+    from lz4_decode import decode_frame
+    from oracle import liblz4_ref
+    o = oracle_mod
+    rng = np.random.default_rng(21)
+    rep = np.tile(o.lcg_genome(32, 900), 200)
+    seqs = [b"", b"ACGT" * 10, bytes(o.lcg_genome(1, 100000)), bytes(o.lcg_genome(2, 70001)), bytes(rep),
+            bytes(rng.integers(0, 256, 90000, dtype=np.uint8)), b"N" * 40000 + bytes(o.lcg_genome(3, 50000)),
+            bytes(o.lcg_genome(4, 30000)), b"A" * 70000, b"ACGTACGTACGTA"]
+    n = len(seqs)
+    items = [(i, -1) for i in range(n)] + [(i, j) for i in range(n) for j in range(n)]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        frames = ctx.frames(items)
+        singles, pairs = ctx.singles(), ctx.pairs()
+    fr = golden["liblz4_frame_sizes"]["frames_hex"]
+    assert frames[0].hex() == fr["empty"] and frames[1].hex() == fr["ACGTx10"]
+    for (i, j), f in zip(items, frames):
+        data = seqs[i] + (seqs[j] if j >= 0 else b"")
+        assert len(f) == (int(singles[i]) if j < 0 else int(pairs[i, j]))          # the size kernels agree
+        assert decode_frame(f) == data, (i, j)
+        if liblz4_ref.available():
+            assert f == liblz4_ref.compress_frame(data), (i, j)
+
+
+def test_save_compression_lz4_cli_and_api(hip, oracle_mod, tmp_path, monkeypatch):
+    """`-s` with `-c lz4`: one .lz4 blob per file and per ordered pair, named as the reference names
+    them, each a valid frame of the right content; compressed_size(..., save_directory=...) likewise."""
+    from click.testing import CliRunner
+    from conftest import write_fasta
+    from lz4_decode import decode_frame
+    from snacc_amd import compressed_size
+    from snacc_amd.cli import cli
+    o = oracle_mod
+    d = tmp_path / "fa"
+    d.mkdir()
+    seqs = {}
+    for i, nbases in enumerate((30000, 70000, 5000)):
+        g = bytes(o.lcg_genome(80 + i, nbases)).decode()
+        write_fasta(d / f"s{i}.fa", [(f"s{i}", g)])
+        seqs[f"s{i}"] = g.encode()
+    blobs = tmp_path / "blobs"
+    blobs.mkdir()
+    monkeypatch.chdir(tmp_path)
+    res = CliRunner().invoke(cli, [str(d), "-o", "o.csv", "-c", "lz4", "-s", str(blobs), "--no-show-progress", "--no-log"])
+    assert res.exit_code == 0, res.output
+    names = sorted(p.name for p in blobs.iterdir())
+    want = sorted([f"s{i}.fa.lz4" for i in range(3)] + [f"s{i}s{j}.fa.lz4" for i in range(3) for j in range(3)])
+    assert names == want
+    assert decode_frame((blobs / "s1.fa.lz4").read_bytes()) == seqs["s1"]
+    assert decode_frame((blobs / "s0s1.fa.lz4").read_bytes()) == seqs["s0"] + seqs["s1"]
+    key, size = compressed_size((d / "s2.fa", d / "s0.fa"), "lz4", save_directory=blobs)
+    blob = (blobs / "s2s0.fa.lz4").read_bytes()
+    assert size == len(blob) + 33 == o.lz4f_size_pair(seqs["s2"], seqs["s0"]) + 33
+    assert decode_frame(blob) == seqs["s2"] + seqs["s0"]

@@ -167,17 +167,6 @@ def test_cli_gzip_flow_matches_reference_cli(golden, oracle_mod, tmp_path, monke
     assert any(ln.startswith("* py-lz4framed: n/a (snacc_amd") for ln in log)
 
 
-def test_cli_rejects_save_compression_with_lz4(tmp_path):
-    from click.testing import CliRunner
-    from snacc_amd.cli import cli
-    f = tmp_path / "a.fa"
-    f.write_text(">a\nACGT\n")
-    blobs = tmp_path / "blobs"
-    blobs.mkdir()
-    res = CliRunner().invoke(cli, [str(f), "-o", str(tmp_path / "o.csv"), "-c", "lz4", "-s", str(blobs), "--no-log"])
-    assert res.exit_code != 0 and "save-compression" in res.output
-
-
 def test_cli_deprecated_flags_warn_and_work(tmp_path, monkeypatch):
     from click.testing import CliRunner
     from snacc_amd.cli import cli

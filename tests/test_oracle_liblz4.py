@@ -81,3 +81,13 @@ def test_raw_block_then_compressible_keeps_partial_table(oracle_mod):
         assert r == liblz4_ref.frame_size(d)
         hits += st["bailouts"] > 0 and st["sequences"] > 1000
     assert hits >= 5
+
+
+def test_frame_decoder_against_liblz4_frames(oracle_mod):
+    """The tests' own LZ4 frame decoder (used for the GPU round-trip property) decodes liblz4's frames."""
+    from lz4_decode import decode_frame
+    rng = np.random.default_rng(17)
+    for kind, n in (("acgt", 0), ("acgt", 37), ("acgt", 70000), ("acgt", 200001), ("runs", 150000),
+                    ("mixed", 300000), ("rand256", 70000), ("repeat", 131072)):
+        d = _gen(rng, kind, n) if n else np.zeros(0, dtype=np.uint8)
+        assert decode_frame(liblz4_ref.compress_frame(d)) == d.tobytes(), (kind, n)
