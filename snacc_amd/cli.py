@@ -130,7 +130,14 @@ def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
                 dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device))
             pairs = all_pairs_hip(ctx, n).astype(np.int64) + GETSIZEOF_OVERHEAD
         else:
-            pairs = ctx.pairs().astype(np.int64) + GETSIZEOF_OVERHEAD
+            # row tiles (a multiple of the 84 chains of a workgroup) so that --show-progress has
+            # something to show on large inputs; results are identical to one call
+            tile = 84 * max(1, (1 << 21) // max(84 * n, 1))
+            starts = range(0, n, tile)
+            if show_progress and n > tile:
+                starts = tqdm(starts, total=(n + tile - 1) // tile)
+            pairs = np.concatenate([ctx.pairs(r0, min(n, r0 + tile)) for r0 in starts]) if n else np.zeros((0, 0), np.uint32)
+            pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
         if save_directory is not None and rank == 0:
             save_lz4_blobs(ctx, files, save_directory)
     finally:
