@@ -716,6 +716,20 @@ int snk_pairs_list(snk_ctx *c, int n_pairs, const int32_t *ij, uint32_t *sizes)
     return SNK_OK;
 }
 
+#ifdef SNK_TRACE
+/* diagnostic build only (not part of the shipped ABI) */
+int snk_debug_trace(unsigned int from, unsigned int *out /* [1 + 4*4096] */, int read)
+{
+    if (!read) {
+        unsigned int zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(snk_trace_n), &zero, 4) != hipSuccess) return -1;
+        return hipMemcpyToSymbol(HIP_SYMBOL(snk_trace_from), &from, 4) == hipSuccess ? 0 : -1;
+    }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(snk_trace_n), 4) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out + 1, HIP_SYMBOL(snk_trace_buf), 4 * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
 #ifdef SNK_STAMP
 /* diagnostic build only (not part of the shipped ABI) */
 int snk_debug_read_stamps(unsigned long long *out8)

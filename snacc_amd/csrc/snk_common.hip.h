@@ -85,3 +85,21 @@ __device__ __forceinline__ uint32_t snk_ld4g(snk_g8 *p)
 {
     return ((__attribute__((address_space(1))) const SnkU32 *)p)->v;   // byte-aligned 4-byte load
 }
+
+// Diagnostic trace (only with -DSNK_TRACE, `make trace`; never shipped): lane 0 of workgroup 0
+// appends (tag, a, b, c) records for stream positions >= snk_trace_from.
+#ifdef SNK_TRACE
+__device__ unsigned int snk_trace_n;
+__device__ unsigned int snk_trace_from;
+__device__ unsigned int snk_trace_buf[4 * 4096];
+__device__ __forceinline__ void snk_trace(unsigned tag, unsigned a, unsigned b, unsigned c, unsigned pos)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pos >= snk_trace_from) {
+        unsigned i = atomicAdd(&snk_trace_n, 1u);
+        if (i < 4096u) { snk_trace_buf[4*i] = tag; snk_trace_buf[4*i+1] = a; snk_trace_buf[4*i+2] = b; snk_trace_buf[4*i+3] = c; }
+    }
+}
+#define SNK_TRACE_REC(tag, a, b, c, pos) snk_trace(tag, a, b, c, pos)
+#else
+#define SNK_TRACE_REC(tag, a, b, c, pos) do { } while (0)
+#endif

@@ -107,6 +107,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             if (L.op + run + 1u + (run + 240u) / 255u <= L.olimit)
                 payload = L.op + 1u + snk_lit_ext(run) + run;
         }
+        SNK_TRACE_REC(1u, L.op, L.anchor, payload | (L.endcode << 28), L.iend);
         L.total += 4u + payload;
         L.pos = L.iend;
         L.in_block = false;
@@ -178,6 +179,7 @@ __device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur
     }
     if (e2 > L.mlimit) e2 = L.mlimit;
     const uint32_t mc = e2 - ip - 4u;
+    SNK_TRACE_REC(2u, cur, cand, (f << 24) | (e2 & 0xFFFFFFu), cur);
     uint32_t op = op0 + 1u;
     bool bail = op + lit + 8u + lit / 255u > L.olimit;
     if (!bail) {
@@ -205,6 +207,12 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     const uint32_t next = cur + L.step;
     SnkWin &w = L.w;
 
+    // Block end, bail-out, or not started yet.  This return must come BEFORE the slide below: a
+    // slide consumes w.nx, and only the refill further down restores the "nx = [rb+32, rb+48)"
+    // invariant the next slide relies on.
+    if (__builtin_expect(next > L.mfl1, 0))
+        return snk_fast_block_step(L, T, tbl, bm, slot, out, status);
+
     // ---- cursor reservoir: slide by 16 bases when needed, refill always in flight ----
     uint32_t o = cur - 4u - w.rb;                            // need 0 <= o <= 15
     {
@@ -215,15 +223,14 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
         o -= sl ? 16u : 0u;
     }
     bool wslow = false;
-    if (__builtin_expect((next > L.mfl1) | (o > 15u) | (!YONLY && cur > w.lim), 0)) {
-        if (next > L.mfl1)                                   // block end, bail-out, or not started yet
-            return snk_fast_block_step(L, T, tbl, bm, slot, out, status);
+    if (__builtin_expect((o > 15u) | (!YONLY && cur > w.lim), 0)) {
         // long jump / source change / seam: re-seat the reservoir
         if (cur >= L.s.lx + 4u)                          snk_win_init(w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
         else if (cur >= 4u && cur + 12u <= L.s.lx)       snk_win_init(w, L.s.arena, L.s.xoff, 0u, L.s.lx - 12u, cur);
         else                                             { w.lim = 0u; wslow = true; }
         o = cur - 4u - w.rb;
     }
+    SNK_TRACE_REC(8u, w.r0, w.r1, w.nx, cur);
     const uint32_t wc = (!YONLY && wslow) ? snk_fetch32(L.s, cur) : __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
 
     // ---- table probe: two LDS round trips (slot LUT, then table + bitmap) ----
@@ -275,6 +282,7 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     const uint32_t big = lit > mc ? lit : mc;
     // both limitedOutput checks of liblz4 reduce to op + lit + 9 > olimit when lit, mc < 15
     const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit) | (e2 >= L.mfl1));
+    SNK_TRACE_REC(4u, cur, cand, (f << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), cur);
     if (__builtin_expect(rare, 0)) {
         snk_fast_match_slow(L, cur, cand, f, L.anchor, L.op);
         return false;
@@ -443,6 +451,8 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
             uint32_t mx = lit > mc ? lit : mc;
             { const uint32_t t1 = b + 11u, t2 = f + 3u; const uint32_t t3 = t1 > t2 ? t1 : t2; mx = mx > t3 ? mx : t3; }
             const bool rare = m & ((mx >= 15u) | (opn > olim6));
+            SNK_TRACE_REC(3u, cur, cand, (f << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), cur);
+            SNK_TRACE_REC(5u, wc, w.rb, nxoff - w.soff, cur);
             const bool pre = (nnext > L.mfl1) | (no > 15u) | (!YONLY && ncur > w.lim);
             L.op = m ? opn : op0;
             L.anchor = m ? e2 : anchor0;

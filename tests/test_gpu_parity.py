@@ -170,6 +170,35 @@ def test_long_matches_and_low_complexity(hip, oracle_mod):
     assert _check_all(hip, oracle_mod, seqs) == 6
 
 
+def _tandem(rng, n, unit_len, rate):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a = np.tile(rng.choice(acgt, unit_len), n // unit_len + 1)[:n].copy()
+    hit = rng.random(n) < rate
+    a[hit] = rng.choice(acgt, int(hit.sum()))
+    return a
+
+
+def test_blocks_ending_in_short_matches(hip, oracle_mod):
+    """Regression (found by tools/gpu_fuzz.py): a 64 KiB block whose last match is 11..31 bases
+    long slid the 2-bit kernel's cursor reservoir right before the block closed and left its
+    look-ahead word stale; the next block then parsed wrong bases.  Mutated tandem repeats end
+    blocks that way often; the single sizes (x part) and the pair sizes (y part, both loop
+    instantiations) must equal the oracle's."""
+    rng = np.random.default_rng(2510)
+    seqs = [_tandem(rng, int(rng.integers(197000, 262000)), int(rng.integers(150, 3000)), rate)
+            for rate in (0.001, 0.02, 0.02, 0.05) for _ in range(12)]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert ctx.num_packed == len(seqs)
+        s = ctx.singles()
+        ij = np.array([(i, (7 * i + 3) % len(seqs)) for i in range(len(seqs))], dtype=np.int32)
+        p = ctx.pairs_list(ij)
+    exp_s = np.array([oracle_mod.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = np.array([oracle_mod.lz4f_size_pair(seqs[i], seqs[j]) for i, j in ij], dtype=np.uint32)
+    assert np.array_equal(s, exp_s), np.flatnonzero(s != exp_s)
+    assert np.array_equal(p, exp_p), np.flatnonzero(p != exp_p)
+
+
 def test_related_genomes_same_ancestor(hip, oracle_mod):
     o = oracle_mod
     anc = o.lcg_genome(40, 180000)

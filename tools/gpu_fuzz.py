@@ -1,0 +1,88 @@
+"""Randomised GPU stress: random sequence sets (lengths, alphabets, repeats), ALL pairs and singles
+through every kernel family, compared with the oracle.  Usage: gpu_fuzz.py SEED0 NSEEDS"""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+import oracle
+from oracle.loader import pairs_mt
+from snacc_amd import hip_backend as hip
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def gen(rng, n, kind):
+    if n == 0:
+        return np.zeros(0, np.uint8)
+    if kind == "acgt":
+        return rng.choice(ACGT, n)
+    if kind == "acgtn":
+        a = rng.choice(ACGT, n)
+        for _ in range(int(rng.integers(1, 6))):
+            s = int(rng.integers(0, n)); a[s:s + int(rng.integers(1, 400))] = ord("N")
+        return a
+    if kind == "soft":
+        a = rng.choice(ACGT, n)
+        for _ in range(int(rng.integers(1, 6))):
+            s = int(rng.integers(0, n)); e = s + int(rng.integers(1, 3000)); a[s:e] |= 0x20
+        return a
+    if kind == "bytes":
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == "aa":
+        return rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8), n)
+    if kind == "repeat":
+        unit = rng.choice(ACGT, int(rng.integers(1, 3000)))
+        a = np.tile(unit, n // len(unit) + 1)[:n].copy()
+        m = rng.random(n) < rng.choice([0.0, 0.001, 0.02])
+        a[m] = rng.choice(ACGT, int(m.sum()))
+        return a
+    if kind == "mix":
+        parts, tot = [], 0
+        while tot < n:
+            k = str(rng.choice(["acgt", "acgtn", "bytes", "repeat", "soft"]))
+            ln = int(rng.integers(1, 90000)); parts.append(gen(rng, ln, k)); tot += ln
+        return np.concatenate(parts)[:n]
+    raise ValueError(kind)
+
+
+def rand_len(rng):
+    c = rng.integers(0, 6)
+    if c == 0: return int(rng.integers(0, 40))
+    if c == 1: return int(rng.integers(40, 33000))
+    if c == 2: return int(65536 * rng.integers(1, 4) + rng.integers(-20, 21))
+    if c == 3: return int(rng.integers(60000, 70000))
+    return int(rng.integers(65537, 260000))
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    profile = str(rng.choice(["pure", "withN", "soft", "anything"]))
+    kinds = {"pure": ["acgt", "repeat"], "withN": ["acgt", "acgtn", "repeat"], "soft": ["acgt", "soft", "acgtn"],
+             "anything": ["acgt", "acgtn", "soft", "bytes", "aa", "repeat", "mix"]}[profile]
+    n = int(rng.integers(6, 15))
+    seqs = [gen(rng, rand_len(rng), str(rng.choice(kinds))) for _ in range(n)]
+    exp_s = np.array([oracle.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = pairs_mt(seqs, 0, n, 16)
+    bad = []
+    for opts in ({}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
+                 {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2}):
+        with hip.HipContext(0, **opts) as ctx:
+            ctx.upload(seqs)
+            s, p = ctx.singles(), ctx.pairs()
+            info = (ctx.num_packed, ctx.num_compact_hashes)
+        if not (np.array_equal(s, exp_s) and np.array_equal(p, exp_p)):
+            bad.append((opts, np.argwhere(p != exp_p)[:4].tolist(), np.argwhere(s != exp_s)[:4].tolist()))
+    return profile, n, [len(x) for x in seqs], info, bad
+
+
+seed0, nseeds = int(sys.argv[1]), int(sys.argv[2])
+fails = 0
+t0 = time.time()
+for seed in range(seed0, seed0 + nseeds):
+    profile, n, lens, info, bad = one(seed)
+    if bad:
+        fails += 1
+        print(f"seed {seed} [{profile}] n={n} lens={lens} packed/hashes={info} MISMATCH {bad}", flush=True)
+    else:
+        print(f"seed {seed} [{profile}] n={n} ok ({time.time() - t0:.0f}s)", flush=True)
+print("FAILED" if fails else "ALL OK", fails)
+sys.exit(1 if fails else 0)
