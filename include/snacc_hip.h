@@ -139,6 +139,21 @@ void snk_free(void *p);
 /* Ingest + snk_upload in one call: the sequence bytes never enter the caller's language runtime. */
 int snk_upload_fasta(snk_ctx *ctx, int n, const char *const *paths, int reverse_complement, int n_threads);
 
+/* ---- gzip / zlib sizes -----------------------------------------------------
+ * Replace, for the batched path, the codec calls of ref:snacc/pairwise_ncd.py:73-74
+ * (gzip.compress -> deflate level 9) and :77-78 (zlib.compress -> deflate level 6) on the resident
+ * sequences.  `level` is 9 or 6.  Sizes are the bytes of the RAW deflate stream zlib 1.2.11 writes
+ * (memLevel 8, 32 KiB window, default strategy), bit exact; the caller adds the wrapper (gzip 18 B,
+ * zlib 6 B) and sys.getsizeof's 33 where those semantics live (Python).
+ *
+ * snk_deflate_prepare builds, once per upload, the per-sequence match index and, once per level, the
+ * symbol stream of every single sequence; the other calls do it implicitly.  Layout of the results
+ * as for snk_singles / snk_pairs / snk_pairs_list (item (i, -1) of a list = sequence i alone). */
+int snk_deflate_prepare(snk_ctx *ctx, int level);
+int snk_deflate_singles(snk_ctx *ctx, int level, uint32_t *sizes /* [n_seq], host */);
+int snk_deflate_pairs(snk_ctx *ctx, int level, int row_begin, int row_end, uint32_t *sizes /* host */);
+int snk_deflate_pairs_list(snk_ctx *ctx, int level, int n_pairs, const int32_t *ij, uint32_t *sizes /* host */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 //               -o ../libsnacc_hip.so snacc_hip.hip
 #include "snk_device.hip.h"
 #include "snacc_hip.h"
+#include "snk_internal.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -43,7 +44,10 @@ struct snk_ctx_impl {
     // resident sequences
     int n = 0, n_packed = 0;
     std::vector<uint32_t> len;
+    std::vector<uint32_t> boff;      // byte offset of every sequence in d_bytes
     std::vector<uint8_t> is_packed;
+    // deflate add-on (snk_deflate.hip): opaque state + its destructor
+    void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
     uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_zero = nullptr;
     const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
@@ -85,7 +89,9 @@ void free_sequences(snk_ctx_impl *c)
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast);
     dfree(c->d_snap_gen); dfree(c->d_single);
-    c->n = 0; c->n_packed = 0; c->len.clear(); c->is_packed.clear(); c->singles_done = false;
+    c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
+    if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
+    c->dfl = nullptr;
 }
 
 // ---- the 5-mer LUTs of the 2-bit kernel ---------------------------------------------------
@@ -304,6 +310,21 @@ int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_bytes, si
 } // namespace
 
 struct snk_ctx : snk_ctx_impl {};
+
+// ---- narrow view of the context for the deflate translation unit (snk_internal.h) ------------
+int snk_internal_view(snk_ctx *c, SnkSeqView *v)
+{
+    if (!c || !v) return SNK_E_ARG;
+    v->device = c->device; v->stream = c->stream; v->n = c->n;
+    v->len = c->len.data(); v->boff = c->boff.data(); v->d_bytes = c->d_bytes;
+    return SNK_OK;
+}
+int snk_internal_fail(snk_ctx *c, int code, const char *msg) { return fail(c, code, "%s", msg); }
+void **snk_internal_dfl_slot(snk_ctx *c, void (***free_fn)(void *))
+{
+    if (free_fn) *free_fn = &c->dfl_free;
+    return &c->dfl;
+}
 
 extern "C" {
 
@@ -582,6 +603,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipMemcpy(c->d_bytes_ptr, bp.data(), n * sizeof(void *), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_packed_off, pp.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_bytes_off, bo.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->boff = bo;
     HIPCHK(c, hipMemcpy(c->d_len, c->len.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_snap_pos, spos.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->d_snap_out, 0, n * 4, c->stream));

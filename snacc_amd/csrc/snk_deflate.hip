@@ -1,0 +1,924 @@
+// snk_deflate.hip -- gzip / zlib compressed SIZES on gfx950.
+//
+// Replaces, for the batched path, the codec calls of
+//   ref:snacc/pairwise_ncd.py:73-74   gzip.compress(sequence)   (zlib deflate level 9)
+//   ref:snacc/pairwise_ncd.py:77-78   zlib.compress(sequence)   (zlib deflate level 6)
+// with bit-exact sizes of the raw deflate stream zlib 1.2.11 writes (deflate_slow, memLevel 8,
+// 32 KiB window); the 18 / 6 wrapper bytes and sys.getsizeof's 33 are added in Python.
+//
+// How the work is organised:
+//  * zlib inserts EVERY position into its hash chains at these levels, so the chain of a position
+//    is a pure function of the data: "earlier positions with the same 15-bit hash of 3 bytes, most
+//    recent first".  Per resident sequence a stable radix sort by hash gives that list with random
+//    access (occ / inv / bucket starts); 64 lanes then test 64 chain candidates at once, in chain
+//    order, honouring zlib's chain budget, distance limits, nice-length early exit and
+//    "first longest wins".
+//  * one wavefront = one parse job; everything deflate_slow decides (lazy evaluation, TOO_FAR,
+//    block cut every 16383 symbols, stored / static / dynamic choice with zlib's exact
+//    build_tree / gen_bitlen / scan_tree) is done by the wave, the trees by lane 0 in LDS.
+//  * exact work elision: a match can reach back 32 506 bytes only, so the symbol stream of x+y
+//    equals x's own stream until just before the seam and y's own stream from the first point,
+//    at least 32 507 bytes after the seam, where both parsers stand right behind a match ending
+//    at the same position.  A pair job therefore restarts from x's stream ~600 bytes before the
+//    seam, parses ~33 K positions, finds that point, and from there only re-cuts y's stored
+//    symbols into blocks (the block phase differs per pair) and prices them.
+#include "snk_internal.h"
+#include "snacc_hip.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t DFL_MAX_DIST = 32506u;      // w_size - MIN_LOOKAHEAD
+constexpr uint32_t DFL_MAX_MATCH = 258u;
+constexpr uint32_t DFL_MIN_LOOKAHEAD = 262u;
+constexpr uint32_t DFL_TOO_FAR = 4096u;
+constexpr uint32_t DFL_BLOCK_SYMS = 16383u;    // lit_bufsize - 1
+constexpr uint32_t DFL_NHASH = 32768u;
+constexpr uint32_t DFL_RESTART_BACK = 600u;    // restart this far before the seam (> 258 + 262)
+constexpr uint32_t DFL_HIST = 320u;            // 0..285 literal/length codes, 288..317 distance codes
+constexpr uint32_t DFL_DOFF = 288u;
+constexpr uint32_t DFL_HEAP = 573u;            // 2 * L_CODES + 1
+constexpr uint32_t DFL_WAVES = 4u;             // wavefronts per workgroup
+
+// LDS of one wavefront (bytes)
+constexpr uint32_t L_HIST = 0;                         // u32[320]
+constexpr uint32_t L_HEAP = L_HIST + 4 * DFL_HIST;     // u16[576]
+constexpr uint32_t L_FREQ = L_HEAP + 2 * 576;          // u16[576]
+constexpr uint32_t L_DAD = L_FREQ + 2 * 576;           // u16[576]
+constexpr uint32_t L_LEN = L_DAD + 2 * 576;            // u16[576]
+constexpr uint32_t L_DEPTH = L_LEN + 2 * 576;          // u8[576]
+constexpr uint32_t L_LLEN = L_DEPTH + 576;             // u8[288]  code lengths of the literal/length tree
+constexpr uint32_t L_DLEN = L_LLEN + 288;              // u8[32]   code lengths of the distance tree
+constexpr uint32_t L_MISC = L_DLEN + 32;               // u32[8]   results of lane 0
+constexpr uint32_t L_WAVE = L_MISC + 32;               // 6848
+
+struct DflSeq {              // one per resident sequence (device + host mirror)
+    uint32_t boff, len;
+    uint64_t ioff;           // element offset into occ / inv
+    uint64_t soff;           // element offset into sym / pos (capacity len + 1)
+    uint64_t coff;           // element offset into cumbits (capacity len / 16383 + 2)
+    uint32_t nsym;           // symbols of the stand-alone stream
+    uint32_t unsafe;         // 1: a stored-block decision near the end depends on the total length
+    uint64_t total_bits;
+    uint32_t rk, rpos;       // restart point: symbol index (clean state) and its stream position
+    uint32_t rkb, rbpos;     // first symbol / stream position of the block that is open at rk
+};
+
+struct DflJob { int32_t xi, yi; uint32_t standalone, out_idx; };
+
+struct DflTables {
+    const uint8_t *bytes;
+    DflSeq *seq;
+    const uint32_t *occ, *inv, *bstart;      // bstart: 32769 entries per sequence
+    uint32_t *sym, *pos;
+    uint64_t *cumbits;
+    uint32_t *rhist;                         // 320 counters per sequence: open block at the restart point
+    uint32_t good, lazy, nice, chain;
+    uint32_t *status;
+};
+
+// ---------------------------------------------------------------------------------------------
+// index build
+// ---------------------------------------------------------------------------------------------
+__global__ void dfl_hash_kernel(const uint8_t *b, uint32_t m, uint16_t *key, uint32_t *val)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (; p < m; p += stride) {
+        key[p] = (uint16_t)((((uint32_t)b[p] << 10) ^ ((uint32_t)b[p + 1] << 5) ^ (uint32_t)b[p + 2]) & 0x7fffu);
+        val[p] = p;
+    }
+}
+
+__global__ void dfl_bstart_kernel(const uint16_t *skey, uint32_t m, uint32_t *bstart)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > DFL_NHASH) return;
+    uint32_t lo = 0, hi = m;                  // first index with key >= h
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)skey[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    bstart[h] = lo;
+}
+
+__global__ void dfl_inv_kernel(const uint32_t *occ, uint32_t m, uint32_t *inv)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (; i < m; i += stride) inv[occ[i]] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the virtual stream x + y (+ what zlib's window holds behind the end of the input)
+// ---------------------------------------------------------------------------------------------
+struct DflStream {
+    const uint8_t *X, *Y;
+    uint32_t lx, ly, n;
+};
+
+// Behind the end of the input zlib's compare loop reads whatever the window buffer still holds:
+// zeros while the window never slid (n <= 64 KiB), else the bytes 32 KiB earlier (the upper half
+// keeps its old content after a slide).
+__device__ __forceinline__ uint32_t dfl_byte(const DflStream &s, uint32_t a)
+{
+    if (a >= s.n) {
+        if (s.n <= 65536u) return 0u;
+        a -= 32768u;
+    }
+    return a < s.lx ? s.X[a] : s.Y[a - s.lx];
+}
+
+__device__ __forceinline__ uint64_t dfl_ld8(const uint8_t *p)
+{
+    struct __attribute__((packed)) U64 { uint64_t v; };
+    return ((const U64 *)p)->v;
+}
+
+__device__ __forceinline__ uint64_t dfl_load8(const DflStream &s, uint32_t a)
+{
+    if (a + 8u <= s.lx) return dfl_ld8(s.X + a);
+    if (a >= s.lx && a + 8u <= s.n) return dfl_ld8(s.Y + (a - s.lx));
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < 8u; ++i) v |= (uint64_t)dfl_byte(s, a + i) << (8u * i);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t dfl_hash3(const DflStream &s, uint32_t a)
+{
+    return ((dfl_byte(s, a) << 10) ^ (dfl_byte(s, a + 1u) << 5) ^ dfl_byte(s, a + 2u)) & 0x7fffu;
+}
+
+// common prefix of the stream at p and at q < p, capped at 258
+__device__ __forceinline__ uint32_t dfl_lcp(const DflStream &s, uint32_t p, uint32_t q)
+{
+    uint32_t t = 0;
+    while (t < DFL_MAX_MATCH) {
+        const uint64_t w = dfl_load8(s, p + t) ^ dfl_load8(s, q + t);
+        if (w) { t += (uint32_t)__builtin_ctzll(w) >> 3; break; }
+        t += 8u;
+    }
+    return t < DFL_MAX_MATCH ? t : DFL_MAX_MATCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trees.c: code lengths and block cost, by lane 0 of the wave, all arrays in the wave's LDS
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dfl_lcode(uint32_t lc)          // lc = match length - 3, 0..255
+{
+    if (lc < 8u) return lc;
+    if (lc == 255u) return 28u;
+    const uint32_t k = 31u - (uint32_t)__builtin_clz(lc);
+    return 4u * k - 4u + ((lc >> (k - 2u)) & 3u);
+}
+__device__ __forceinline__ uint32_t dfl_dcode(uint32_t d)           // d = distance - 1, 0..32767
+{
+    if (d < 4u) return d;
+    const uint32_t k = 31u - (uint32_t)__builtin_clz(d);
+    return 2u * k + ((d >> (k - 1u)) & 1u);
+}
+__device__ __forceinline__ uint32_t dfl_lextra(uint32_t code)       // code 0..28 (length codes)
+{
+    return (code < 8u || code == 28u) ? 0u : (code >> 2) - 1u;
+}
+__device__ __forceinline__ uint32_t dfl_dextra(uint32_t code) { return code < 4u ? 0u : (code >> 1) - 1u; }
+__device__ __forceinline__ uint32_t dfl_static_llen(uint32_t n) { return n <= 143u ? 8u : (n <= 255u ? 9u : (n <= 279u ? 7u : 8u)); }
+
+struct DflLds {
+    uint32_t *hist;
+    uint16_t *heap, *freq, *dad, *len;
+    uint8_t *depth, *llen, *dlen;
+    uint32_t *misc;
+};
+
+#define DFL_SMALLER(n, m) (L.freq[n] < L.freq[m] || (L.freq[n] == L.freq[m] && L.depth[n] <= L.depth[m]))
+
+__device__ __forceinline__ void dfl_pqdownheap(const DflLds &L, int heap_len, int k)
+{
+    const int v = L.heap[k];
+    int j = k << 1;
+    while (j <= heap_len) {
+        if (j < heap_len && DFL_SMALLER(L.heap[j + 1], L.heap[j])) j++;
+        if (DFL_SMALLER(v, L.heap[j])) break;
+        L.heap[k] = L.heap[j];
+        k = j;
+        j <<= 1;
+    }
+    L.heap[k] = (uint16_t)v;
+}
+
+// kind 0: literal/length tree, 1: distance tree, 2: bit-length tree.  Frequencies are in L.freq[0..elems).
+// Leaves lengths in L.len[0..elems); returns max_code; adds to opt_len / static_len.
+__device__ int dfl_build_tree(const DflLds &L, int kind, long &opt_len, long &static_len)
+{
+    const int elems = kind == 0 ? 286 : (kind == 1 ? 30 : 19);
+    const int max_length = kind == 2 ? 7 : 15;
+    int n, m, max_code = -1, node, h, bits, overflow = 0, heap_len = 0, heap_max = (int)DFL_HEAP;
+    uint16_t bl_count[16];
+
+    for (n = 0; n < elems; n++) {
+        if (L.freq[n] != 0) { L.heap[++heap_len] = (uint16_t)(max_code = n); L.depth[n] = 0; }
+        else L.len[n] = 0;
+    }
+    while (heap_len < 2) {
+        node = (max_code < 2 ? ++max_code : 0);
+        L.heap[++heap_len] = (uint16_t)node;
+        L.freq[node] = 1;
+        L.depth[node] = 0;
+        opt_len--;
+        if (kind == 0) static_len -= (long)dfl_static_llen((uint32_t)node);
+        else if (kind == 1) static_len -= 5;
+    }
+    for (n = heap_len / 2; n >= 1; n--) dfl_pqdownheap(L, heap_len, n);
+    node = elems;
+    do {
+        n = L.heap[1];
+        L.heap[1] = L.heap[heap_len--];
+        dfl_pqdownheap(L, heap_len, 1);
+        m = L.heap[1];
+        L.heap[--heap_max] = (uint16_t)n;
+        L.heap[--heap_max] = (uint16_t)m;
+        L.freq[node] = (uint16_t)(L.freq[n] + L.freq[m]);
+        L.depth[node] = (uint8_t)((L.depth[n] >= L.depth[m] ? L.depth[n] : L.depth[m]) + 1);
+        L.dad[n] = L.dad[m] = (uint16_t)node;
+        L.heap[1] = (uint16_t)node++;
+        dfl_pqdownheap(L, heap_len, 1);
+    } while (heap_len >= 2);
+    L.heap[--heap_max] = L.heap[1];
+
+    for (bits = 0; bits < 16; bits++) bl_count[bits] = 0;
+    L.len[L.heap[heap_max]] = 0;
+    for (h = heap_max + 1; h < (int)DFL_HEAP; h++) {
+        n = L.heap[h];
+        bits = L.len[L.dad[n]] + 1;
+        if (bits > max_length) { bits = max_length; overflow++; }
+        L.len[n] = (uint16_t)bits;
+        if (n > max_code) continue;
+        bl_count[bits]++;
+        int xbits = 0, slen = 0;
+        if (kind == 0) { if (n >= 257) xbits = (int)dfl_lextra((uint32_t)n - 257u); slen = (int)dfl_static_llen((uint32_t)n); }
+        else if (kind == 1) { xbits = (int)dfl_dextra((uint32_t)n); slen = 5; }
+        else xbits = n == 16 ? 2 : (n == 17 ? 3 : (n == 18 ? 7 : 0));
+        opt_len += (long)L.freq[n] * (bits + xbits);
+        if (kind != 2) static_len += (long)L.freq[n] * (slen + xbits);
+    }
+    if (overflow > 0) {
+        do {
+            bits = max_length - 1;
+            while (bl_count[bits] == 0) bits--;
+            bl_count[bits]--;
+            bl_count[bits + 1] += 2;
+            bl_count[max_length]--;
+            overflow -= 2;
+        } while (overflow > 0);
+        for (bits = max_length; bits != 0; bits--) {
+            n = bl_count[bits];
+            while (n != 0) {
+                m = L.heap[--h];
+                if (m > max_code) continue;
+                if (L.len[m] != (uint16_t)bits) {
+                    opt_len += ((long)bits - (long)L.len[m]) * (long)L.freq[m];
+                    L.len[m] = (uint16_t)bits;
+                }
+                n--;
+            }
+        }
+    }
+    return max_code;
+}
+
+// scan_tree over saved code lengths; adds to the bit-length frequencies bl[0..19)
+__device__ void dfl_scan_tree(const uint8_t *lens, int max_code, uint16_t *bl)
+{
+    int prevlen = -1, curlen, nextlen = lens[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    for (int n = 0; n <= max_code; n++) {
+        curlen = nextlen;
+        nextlen = n == max_code ? 0xffff : lens[n + 1];          // zlib's guard entry
+        if (++count < max_count && curlen == nextlen) continue;
+        else if (count < min_count) bl[curlen] = (uint16_t)(bl[curlen] + count);
+        else if (curlen != 0) { if (curlen != prevlen) bl[curlen]++; bl[16]++; }
+        else if (count <= 10) bl[17]++;
+        else bl[18]++;
+        count = 0;
+        prevlen = curlen;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+        else { max_count = 7; min_count = 4; }
+    }
+}
+
+// opt_len / static_len of the block whose symbol counts are in L.hist (lane 0 only)
+__device__ void dfl_block_lengths(const DflLds &L, long &opt_len, long &static_len)
+{
+    const uint8_t bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    opt_len = 0; static_len = 0;
+    for (int n = 0; n < 286; n++) L.freq[n] = (uint16_t)L.hist[n];
+    const int lmax = dfl_build_tree(L, 0, opt_len, static_len);
+    for (int n = 0; n < 286; n++) L.llen[n] = (uint8_t)L.len[n];
+    for (int n = 0; n < 30; n++) L.freq[n] = (uint16_t)L.hist[DFL_DOFF + n];
+    const int dmax = dfl_build_tree(L, 1, opt_len, static_len);
+    for (int n = 0; n < 30; n++) L.dlen[n] = (uint8_t)L.len[n];
+    for (int n = 0; n < 19; n++) L.freq[n] = 0;
+    dfl_scan_tree(L.llen, lmax, L.freq);
+    dfl_scan_tree(L.dlen, dmax, L.freq);
+    dfl_build_tree(L, 2, opt_len, static_len);
+    int max_blindex;
+    for (max_blindex = 18; max_blindex >= 3; max_blindex--)
+        if (L.len[bl_order[max_blindex]] != 0) break;
+    opt_len += 3 * ((long)max_blindex + 1) + 5 + 5 + 4;
+}
+
+// Start of zlib's window (stream position of window[0]) when the parser stands at loop top p0.
+// The window slides by 32 KiB at the first loop top where fewer than 262 bytes of look-ahead are
+// left in it; `n` enters because the last, partly filled window slides one byte earlier.
+__device__ __forceinline__ uint32_t dfl_window_base(uint32_t p0, uint32_t n)
+{
+    uint32_t base = p0 >= 65275u ? ((p0 - 65275u) >> 15) << 15 : 0u;
+    for (;;) {
+        const uint32_t t = base + (n <= base + 65535u ? 65274u : 65275u);
+        if (p0 < t) break;
+        base += 32768u;
+    }
+    return base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one parse job per wavefront
+// ---------------------------------------------------------------------------------------------
+struct DflWave {
+    DflLds L;
+    uint32_t lane;
+    // block accounting
+    uint64_t bits;
+    uint32_t bcount;          // symbols in the open block
+    uint32_t block_start;     // stream position where it starts
+    uint32_t nblk;            // blocks closed so far (stand-alone jobs store cumbits per block)
+    uint32_t unsafe;
+    // output of the stand-alone stream
+    bool store;
+    uint32_t *sym, *pos;
+    uint64_t *cumbits;
+    uint32_t nsym;
+    uint32_t n;               // stream length
+};
+
+__device__ __forceinline__ void dfl_hist_reset(DflWave &w)
+{
+    for (uint32_t i = w.lane; i < DFL_HIST; i += 64u) w.L.hist[i] = i == 256u ? 1u : 0u;
+}
+
+// Close the open block: p0 = loop top of the iteration that closes it, end = strstart at that moment.
+__device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
+{
+    if (w.lane == 0) {
+        long opt_len, static_len;
+        dfl_block_lengths(w.L, opt_len, static_len);
+        uint32_t opt_lenb = (uint32_t)((opt_len + 3 + 7) >> 3);
+        const uint32_t static_lenb = (uint32_t)((static_len + 3 + 7) >> 3);
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+        const uint32_t stored_len = end - w.block_start;
+        const bool stored_wins = stored_len + 4u <= opt_lenb;
+        const bool have_buf = w.block_start >= dfl_window_base(p0, w.n);
+        uint32_t kind = (stored_wins && have_buf) ? 0u : (static_lenb == opt_lenb ? 1u : 2u);
+        // would the decision change if the stream went on (pair streams reuse x's blocks)?
+        const bool have_buf_inf = w.block_start >= dfl_window_base(p0, 0xFFFFFFFFu);
+        w.L.misc[0] = kind;
+        w.L.misc[1] = kind == 0u ? stored_len : (kind == 1u ? (uint32_t)static_len : (uint32_t)opt_len);
+        w.L.misc[2] = (stored_wins && have_buf != have_buf_inf) ? 1u : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t kind = w.L.misc[0], val = w.L.misc[1];
+    w.unsafe |= w.L.misc[2];
+    if (kind == 0u) {
+        w.bits += 3u;
+        w.bits = (w.bits + 7ull) & ~7ull;
+        w.bits += 32ull + 8ull * val;
+    } else {
+        w.bits += 3ull + val;
+    }
+    if (last) w.bits = (w.bits + 7ull) & ~7ull;
+    if (w.store && w.lane == 0) w.cumbits[w.nblk] = w.bits;
+    w.nblk++;
+    __builtin_amdgcn_wave_barrier();
+    dfl_hist_reset(w);
+    __builtin_amdgcn_wave_barrier();
+    w.bcount = 0;
+    w.block_start = end;
+}
+
+// One symbol from the parser (wave-uniform arguments).  is_match: len/dist valid.
+__device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, uint32_t lit, uint32_t len, uint32_t dist, bool tail = false)
+{
+    if (w.lane == 0) {
+        if (is_match) {
+            w.L.hist[257u + dfl_lcode(len - 3u)]++;
+            w.L.hist[DFL_DOFF + dfl_dcode(dist - 1u)]++;
+        } else {
+            w.L.hist[lit]++;
+        }
+        if (w.store) {
+            w.sym[w.nsym] = is_match ? (0x80000000u | ((len - 3u) << 16) | dist) : lit;
+            w.pos[w.nsym] = q;
+        }
+    }
+    w.nsym++;
+    w.bcount++;
+    // (the literal zlib tallies after its main loop never closes a block: the final flush does)
+    if (w.bcount == DFL_BLOCK_SYMS && !tail) {
+        __builtin_amdgcn_wave_barrier();
+        dfl_flush(w, false, q + 1u, is_match ? q + len : q + 1u);
+    }
+}
+
+__global__ void __launch_bounds__(64 * DFL_WAVES)
+dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
+{
+    extern __shared__ __align__(16) uint8_t dfl_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t jid = blockIdx.x * DFL_WAVES + wave;
+    if (jid >= njobs) return;
+    const DflJob job = jobs[jid];
+
+    uint8_t *lds = dfl_lds + wave * L_WAVE;
+    DflWave w;
+    w.L.hist = (uint32_t *)(lds + L_HIST); w.L.heap = (uint16_t *)(lds + L_HEAP); w.L.freq = (uint16_t *)(lds + L_FREQ);
+    w.L.dad = (uint16_t *)(lds + L_DAD); w.L.len = (uint16_t *)(lds + L_LEN); w.L.depth = lds + L_DEPTH;
+    w.L.llen = lds + L_LLEN; w.L.dlen = lds + L_DLEN; w.L.misc = (uint32_t *)(lds + L_MISC);
+    w.lane = lane;
+
+    const DflSeq sx = T.seq[job.xi];
+    const bool pair = job.yi >= 0;
+    DflSeq sy = sx;
+    if (pair) sy = T.seq[job.yi];
+    DflStream S;
+    S.X = T.bytes + sx.boff; S.lx = sx.len;
+    S.Y = pair ? T.bytes + sy.boff : S.X; S.ly = pair ? sy.len : 0u;
+    S.n = S.lx + S.ly;
+    const uint32_t lx = S.lx, n = S.n;
+    const uint32_t *occx = T.occ + sx.ioff, *invx = T.inv + sx.ioff, *bsx = T.bstart + (size_t)job.xi * (DFL_NHASH + 1u);
+    const uint32_t *occy = T.occ + sy.ioff, *invy = T.inv + sy.ioff, *bsy = T.bstart + (size_t)(pair ? job.yi : job.xi) * (DFL_NHASH + 1u);
+
+    // the two seam positions whose 3-byte hash mixes x and y
+    const bool has1 = pair && lx >= 1u && lx - 1u + 3u <= n;
+    const bool has2 = pair && lx >= 2u && lx - 2u + 3u <= n;
+    const uint32_t hs1 = has1 ? dfl_hash3(S, lx - 1u) : 0xFFFFFFFFu;
+    const uint32_t hs2 = has2 ? dfl_hash3(S, lx - 2u) : 0xFFFFFFFFu;
+
+    w.n = n; w.unsafe = 0; w.nblk = 0;
+    w.store = job.standalone != 0u;
+    w.sym = T.sym + sx.soff; w.pos = T.pos + sx.soff; w.cumbits = T.cumbits + sx.coff;
+
+    uint32_t p;
+    const bool restart = !w.store && sx.unsafe == 0u && sx.rk != 0u;
+    if (restart) {
+        for (uint32_t i = lane; i < DFL_HIST; i += 64u) w.L.hist[i] = T.rhist[(size_t)job.xi * DFL_HIST + i];
+        const uint32_t blocks_before = sx.rkb / DFL_BLOCK_SYMS;
+        w.bits = blocks_before ? (T.cumbits + sx.coff)[blocks_before - 1u] : 0ull;
+        w.nblk = blocks_before;
+        w.bcount = sx.rk - sx.rkb;
+        w.nsym = sx.rk;
+        w.block_start = sx.rbpos;
+        p = sx.rpos;
+    } else {
+        dfl_hist_reset(w);
+        w.bits = 0; w.bcount = 0; w.nsym = 0; w.block_start = 0; p = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const bool try_sync = pair && !w.store && S.ly > 65536u && sy.nsym != 0u;
+    const uint32_t *symy = T.sym + sy.soff, *posy = T.pos + sy.soff;
+    uint32_t sync_k = 0xFFFFFFFFu;
+
+    uint32_t match_length = 2u, match_start = 0u;
+    bool match_available = false;
+
+    while (p < n) {
+        const uint32_t la = n - p;
+        const uint32_t prev_length = match_length, prev_match = match_start;
+        match_length = 2u;
+        if (la >= 3u && prev_length < T.lazy) {
+            // ---- the chain of p: earlier positions with the same hash, most recent first ----
+            const uint32_t h = dfl_hash3(S, p);
+            uint32_t ny = 0, ybase = 0, nsp = 0, sp0 = 0, sp1 = 0, nx = 0, xtop = 0;
+            if (p >= lx) {
+                const uint32_t r = invy[p - lx] - bsy[h];
+                ny = r; ybase = bsy[h] + r - 1u;
+                if (hs1 == h) { sp0 = lx - 1u; nsp = 1u; }
+                if (hs2 == h) { if (nsp) sp1 = lx - 2u; else sp0 = lx - 2u; nsp++; }
+                if (pair) { nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u; }
+            } else if (p + 3u <= lx) {
+                nx = invx[p] - bsx[h]; xtop = bsx[h] + nx - 1u;
+            } else {
+                if (p == lx - 1u && hs2 == h) { sp0 = lx - 2u; nsp = 1u; }
+                nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u;
+            }
+            const uint32_t total = ny + nsp + nx;
+            if (total != 0u) {
+                uint32_t chain = T.chain;
+                if (prev_length >= T.good) chain >>= 2;
+                const uint32_t nice = T.nice > la ? la : T.nice;
+                const uint32_t lim = total < chain ? total : chain;
+                uint32_t best_len = prev_length;
+                bool first = true;
+                for (uint32_t j0 = 0; j0 < lim; j0 += 64u) {
+                    const uint32_t j = j0 + lane;
+                    uint32_t q = 0;
+                    bool valid = j < lim;
+                    if (valid) {
+                        if (j < ny) q = lx + occy[ybase - j];
+                        else if (j - ny < nsp) q = (j - ny) == 0u ? sp0 : sp1;
+                        else q = occx[xtop - (j - ny - nsp)];
+                        const uint32_t dist = p - q;
+                        valid = q != 0u && dist <= (j == 0u ? DFL_MAX_DIST : DFL_MAX_DIST - 1u);
+                    }
+                    // the walk ends at the first candidate that is out of range
+                    const uint64_t bad = __builtin_amdgcn_ballot_w64(!valid);
+                    const uint32_t nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                    if (first && nvalid == 0u) break;             // hash_head unusable: no search at all
+                    first = false;
+                    const bool act = lane < nvalid;
+                    const uint32_t len = act ? dfl_lcp(S, p, q) : 0u;
+                    // zlib stops at the first candidate that improves on the best so far and reaches nice_match
+                    const uint32_t need = nice > best_len + 1u ? nice : best_len + 1u;
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(act && len >= need);
+                    const uint32_t upto = hit ? (uint32_t)__builtin_ctzll(hit) + 1u : nvalid;
+                    uint32_t m = lane < upto ? len : 0u;
+                    for (uint32_t o = 32u; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, (int)o, 64); m = t > m ? t : m; }
+                    if (m > best_len) {
+                        const uint64_t who = __builtin_amdgcn_ballot_w64(lane < upto && len == m);
+                        const uint32_t src = (uint32_t)__builtin_ctzll(who);
+                        match_start = (uint32_t)__shfl((int)q, (int)src, 64);
+                        best_len = m;
+                    }
+                    if (hit || nvalid < 64u) break;
+                }
+                if (!first) {
+                    match_length = best_len <= la ? best_len : la;
+                    if (match_length == 3u && p - match_start > DFL_TOO_FAR) match_length = 2u;
+                }
+            }
+        }
+        if (prev_length >= 3u && match_length <= prev_length) {
+            const uint32_t q = p - 1u;
+            dfl_emit(w, true, q, 0u, prev_length, q - prev_match);
+            p = q + prev_length;
+            match_available = false;
+            match_length = 2u;
+            // both parsers right behind a match, and x out of reach: from here on y's own stream
+            if (try_sync && p >= lx + DFL_MAX_DIST + 1u && p < n) {
+                const uint32_t want = p - lx;
+                uint32_t lo = 0, hi = sy.nsym;                   // first k with posy[k] >= want
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (posy[mid] < want) lo = mid + 1u; else hi = mid; }
+                if (lo < sy.nsym && lo > 0u && posy[lo] == want && (symy[lo - 1u] >> 31)) { sync_k = lo; break; }
+            }
+        } else if (match_available) {
+            dfl_emit(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u);
+            p++;
+        } else {
+            match_available = true;
+            p++;
+        }
+    }
+
+    if (sync_k != 0xFFFFFFFFu) {
+        // ---- y's own symbols from sync_k on, re-cut into this stream's blocks ----
+        uint32_t k = sync_k;
+        __builtin_amdgcn_wave_barrier();
+        while (k < sy.nsym) {
+            uint32_t m = sy.nsym - k;
+            if (m > 64u) m = 64u;
+            if (m > DFL_BLOCK_SYMS - w.bcount) m = DFL_BLOCK_SYMS - w.bcount;
+            uint32_t s = 0;
+            if (lane < m) {
+                s = symy[k + lane];
+                if (s >> 31) {
+                    atomicAdd(&w.L.hist[257u + dfl_lcode((s >> 16) & 0x7fffu)], 1u);
+                    atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((s & 0xffffu) - 1u)], 1u);
+                } else {
+                    atomicAdd(&w.L.hist[s], 1u);
+                }
+            }
+            k += m; w.bcount += m; w.nsym += m;
+            if (w.bcount == DFL_BLOCK_SYMS) {
+                const uint32_t sl = (uint32_t)__shfl((int)s, (int)(m - 1u), 64);
+                const uint32_t q = lx + posy[k - 1u];
+                if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
+                __builtin_amdgcn_wave_barrier();
+                dfl_flush(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (match_available) {
+        dfl_emit(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
+    }
+    __builtin_amdgcn_wave_barrier();
+    dfl_flush(w, true, n, n);
+
+    if (lane == 0) {
+        out[job.out_idx] = (uint32_t)(w.bits >> 3);
+        if (w.store) {
+            DflSeq *d = T.seq + job.xi;
+            d->nsym = w.nsym - 0u;
+            d->unsafe = w.unsafe;
+            d->total_bits = w.bits;
+        }
+    }
+}
+
+// Restart record of every sequence: the last clean state at least DFL_RESTART_BACK bytes before
+// its end, and the symbol counts of the block that is open there.  One wave per sequence.
+__global__ void __launch_bounds__(64) dfl_restart_kernel(DflTables T, uint32_t nseq)
+{
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    if (g >= nseq) return;
+    __shared__ uint32_t hist[DFL_HIST];
+    DflSeq *d = T.seq + g;
+    const uint32_t *sym = T.sym + d->soff, *pos = T.pos + d->soff;
+    const uint32_t nsym = d->nsym, len = d->len;
+    uint32_t k = 0;
+    if (len > DFL_RESTART_BACK && nsym != 0u) {
+        const uint32_t target = len - DFL_RESTART_BACK;
+        uint32_t lo = 0, hi = nsym;                              // first k with pos[k] > target
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pos[mid] <= target) lo = mid + 1u; else hi = mid; }
+        k = lo ? lo - 1u : 0u;
+        while (k > 0u && !(sym[k - 1u] >> 31)) k--;
+    }
+    const uint32_t kb = k / DFL_BLOCK_SYMS * DFL_BLOCK_SYMS;
+    for (uint32_t i = lane; i < DFL_HIST; i += 64u) hist[i] = i == 256u ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t i = kb + lane; i < k; i += 64u) {
+        const uint32_t s = sym[i];
+        if (s >> 31) {
+            atomicAdd(&hist[257u + dfl_lcode((s >> 16) & 0x7fffu)], 1u);
+            atomicAdd(&hist[DFL_DOFF + dfl_dcode((s & 0xffffu) - 1u)], 1u);
+        } else {
+            atomicAdd(&hist[s], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < DFL_HIST; i += 64u) T.rhist[(size_t)g * DFL_HIST + i] = hist[i];
+    if (lane == 0) {
+        d->rk = k;
+        d->rpos = k < nsym ? pos[k] : 0u;
+        d->rkb = kb;
+        d->rbpos = kb < nsym ? pos[kb] : 0u;
+        if (k >= nsym) d->rk = 0u;                               // nothing to restart from
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct DflState {
+    int device = 0;
+    int n = 0;
+    int level = 0;                       // level the symbol streams were built for (0 = none)
+    bool indexed = false;
+    std::vector<DflSeq> seq;
+    DflSeq *d_seq = nullptr;
+    uint32_t *d_occ = nullptr, *d_inv = nullptr, *d_bstart = nullptr;
+    uint32_t *d_sym = nullptr, *d_pos = nullptr, *d_rhist = nullptr, *d_status = nullptr;
+    uint64_t *d_cumbits = nullptr;
+    DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
+    uint32_t *d_out = nullptr; size_t out_cap = 0;
+    std::vector<uint32_t> single;        // raw stream bytes of every sequence at `level`
+};
+
+template <typename P> void dfree(P *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
+
+void dfl_destroy(void *v)
+{
+    DflState *s = (DflState *)v;
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_inv); dfree(s->d_bstart); dfree(s->d_sym); dfree(s->d_pos);
+    dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
+    delete s;
+}
+
+#define DCHK(c, call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            char m_[384];                                                                    \
+            snprintf(m_, sizeof m_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return snk_internal_fail((c), SNK_E_HIP, m_);                                    \
+        }                                                                                    \
+    } while (0)
+
+bool level_config(int level, DflTables &T)
+{
+    if (level == 9) { T.good = 32; T.lazy = 258; T.nice = 258; T.chain = 4096; return true; }
+    if (level == 6) { T.good = 8; T.lazy = 16; T.nice = 128; T.chain = 128; return true; }
+    return false;
+}
+
+DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
+{
+    DflTables T{};
+    T.bytes = v.d_bytes; T.seq = s->d_seq; T.occ = s->d_occ; T.inv = s->d_inv; T.bstart = s->d_bstart;
+    T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
+    level_config(level, T);
+    return T;
+}
+
+int dfl_get(snk_ctx *c, SnkSeqView &v, DflState *&s)
+{
+    int rc = snk_internal_view(c, &v);
+    if (rc != SNK_OK) return rc;
+    if (v.n <= 0) return snk_internal_fail(c, SNK_E_STATE, "no sequences resident (call snk_upload first)");
+    void (**free_fn)(void *) = nullptr;
+    void **slot = snk_internal_dfl_slot(c, &free_fn);
+    if (!*slot) {
+        DflState *ns = new (std::nothrow) DflState();
+        if (!ns) return snk_internal_fail(c, SNK_E_HIP, "out of host memory");
+        ns->device = v.device; ns->n = v.n;
+        *slot = ns; *free_fn = dfl_destroy;
+    }
+    s = (DflState *)*slot;
+    return SNK_OK;
+}
+
+int dfl_ensure_scratch(snk_ctx *c, DflState *s, size_t njobs)
+{
+    if (njobs > s->jobs_cap) {
+        dfree(s->d_jobs);
+        DCHK(c, hipMalloc((void **)&s->d_jobs, njobs * sizeof(DflJob)));
+        s->jobs_cap = njobs;
+    }
+    if (njobs > s->out_cap) {
+        dfree(s->d_out);
+        DCHK(c, hipMalloc((void **)&s->d_out, njobs * sizeof(uint32_t)));
+        s->out_cap = njobs;
+    }
+    return SNK_OK;
+}
+
+int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const std::vector<DflJob> &jobs, uint32_t *host_out)
+{
+    if (jobs.empty()) return SNK_OK;
+    int rc = dfl_ensure_scratch(c, s, jobs.size());
+    if (rc != SNK_OK) return rc;
+    DCHK(c, hipMemcpyAsync(s->d_jobs, jobs.data(), jobs.size() * sizeof(DflJob), hipMemcpyHostToDevice, v.stream));
+    const DflTables T = make_tables(s, v, level);
+    const uint32_t nj = (uint32_t)jobs.size();
+    hipLaunchKernelGGL(dfl_parse_kernel, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
+                       v.stream, T, s->d_jobs, nj, s->d_out);
+    DCHK(c, hipGetLastError());
+    if (host_out) {
+        DCHK(c, hipMemcpyAsync(host_out, s->d_out, jobs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
+    }
+    DCHK(c, hipStreamSynchronize(v.stream));
+    return SNK_OK;
+}
+
+int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
+{
+    const size_t n = (size_t)v.n;
+    s->seq.assign(n, DflSeq{});
+    uint64_t itot = 0, stot = 0, ctot = 0;
+    uint32_t maxlen = 0;
+    for (size_t g = 0; g < n; ++g) {
+        DflSeq &q = s->seq[g];
+        q.boff = v.boff[g]; q.len = v.len[g];
+        q.ioff = itot; itot += (uint64_t)q.len + 1u;
+        q.soff = stot; stot += (uint64_t)q.len + 1u;
+        q.coff = ctot; ctot += (uint64_t)q.len / DFL_BLOCK_SYMS + 2u;
+        maxlen = std::max(maxlen, q.len);
+    }
+    DCHK(c, hipMalloc((void **)&s->d_seq, n * sizeof(DflSeq)));
+    DCHK(c, hipMalloc((void **)&s->d_occ, itot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_inv, itot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_bstart, n * (DFL_NHASH + 1u) * 4));
+    DCHK(c, hipMalloc((void **)&s->d_sym, stot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_pos, stot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_cumbits, ctot * 8));
+    DCHK(c, hipMalloc((void **)&s->d_rhist, n * DFL_HIST * 4));
+    DCHK(c, hipMalloc((void **)&s->d_status, 4));
+    DCHK(c, hipMemsetAsync(s->d_status, 0, 4, v.stream));
+    DCHK(c, hipMemsetAsync(s->d_inv, 0, itot * 4, v.stream));
+
+    uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    const size_t cap = (size_t)maxlen + 1u;
+    DCHK(c, hipMalloc((void **)&d_key, cap * 2));
+    DCHK(c, hipMalloc((void **)&d_skey, cap * 2));
+    DCHK(c, hipMalloc((void **)&d_val, cap * 4));
+    {
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_skey, d_val, s->d_occ, (int)cap, 0, 15, v.stream);
+        if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort sizing failed");
+    }
+    DCHK(c, hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    for (size_t g = 0; g < n; ++g) {
+        const DflSeq &q = s->seq[g];
+        const uint32_t m = q.len >= 3u ? q.len - 2u : 0u;
+        uint32_t *bst = s->d_bstart + g * (DFL_NHASH + 1u);
+        if (m) {
+            const uint32_t grid = std::min<uint32_t>((m + 255u) / 256u, 4096u);
+            hipLaunchKernelGGL(dfl_hash_kernel, dim3(grid), dim3(256), 0, v.stream, v.d_bytes + q.boff, m, d_key, d_val);
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_skey, d_val, s->d_occ + q.ioff, (int)m, 0, 15, v.stream);
+            if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort failed");
+            hipLaunchKernelGGL(dfl_inv_kernel, dim3(grid), dim3(256), 0, v.stream, s->d_occ + q.ioff, m, s->d_inv + q.ioff);
+        }
+        hipLaunchKernelGGL(dfl_bstart_kernel, dim3((DFL_NHASH + 1u + 255u) / 256u), dim3(256), 0, v.stream, d_skey, m, bst);
+    }
+    DCHK(c, hipGetLastError());
+    DCHK(c, hipStreamSynchronize(v.stream));
+    dfree(d_key); dfree(d_skey); dfree(d_val);
+    if (d_tmp) (void)hipFree(d_tmp);
+    s->indexed = true;
+    return SNK_OK;
+}
+
+int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
+{
+    DflTables cfg{};
+    if (!level_config(level, cfg)) return snk_internal_fail(c, SNK_E_ARG, "deflate level must be 9 (gzip) or 6 (zlib)");
+    int rc = dfl_get(c, v, s);
+    if (rc != SNK_OK) return rc;
+    DCHK(c, hipSetDevice(v.device));
+    if (!s->indexed) { rc = dfl_build_index(c, s, v); if (rc != SNK_OK) return rc; }
+    if (s->level == level) return SNK_OK;
+    // stand-alone stream of every sequence at this level
+    for (auto &q : s->seq) { q.nsym = 0; q.unsafe = 0; q.total_bits = 0; q.rk = q.rpos = q.rkb = q.rbpos = 0; }
+    DCHK(c, hipMemcpy(s->d_seq, s->seq.data(), s->seq.size() * sizeof(DflSeq), hipMemcpyHostToDevice));
+    std::vector<DflJob> jobs((size_t)v.n);
+    for (int g = 0; g < v.n; ++g) jobs[(size_t)g] = DflJob{g, -1, 1u, (uint32_t)g};
+    s->single.assign((size_t)v.n, 0u);
+    rc = dfl_launch(c, s, v, level, jobs, s->single.data());
+    if (rc != SNK_OK) return rc;
+    const DflTables T = make_tables(s, v, level);
+    hipLaunchKernelGGL(dfl_restart_kernel, dim3((uint32_t)v.n), dim3(64), 0, v.stream, T, (uint32_t)v.n);
+    DCHK(c, hipGetLastError());
+    DCHK(c, hipStreamSynchronize(v.stream));
+    DCHK(c, hipMemcpy(s->seq.data(), s->d_seq, s->seq.size() * sizeof(DflSeq), hipMemcpyDeviceToHost));
+    s->level = level;
+    return SNK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int snk_deflate_prepare(snk_ctx *c, int level)
+{
+    if (!c) return SNK_E_ARG;
+    SnkSeqView v; DflState *s = nullptr;
+    return dfl_prepare(c, level, v, s);
+}
+
+int snk_deflate_singles(snk_ctx *c, int level, uint32_t *sizes)
+{
+    if (!c || !sizes) return c ? snk_internal_fail(c, SNK_E_ARG, "sizes is NULL") : SNK_E_ARG;
+    SnkSeqView v; DflState *s = nullptr;
+    int rc = dfl_prepare(c, level, v, s);
+    if (rc != SNK_OK) return rc;
+    std::copy(s->single.begin(), s->single.end(), sizes);
+    return SNK_OK;
+}
+
+int snk_deflate_pairs(snk_ctx *c, int level, int row_begin, int row_end, uint32_t *sizes)
+{
+    if (!c || !sizes) return c ? snk_internal_fail(c, SNK_E_ARG, "sizes is NULL") : SNK_E_ARG;
+    SnkSeqView v; DflState *s = nullptr;
+    int rc = dfl_prepare(c, level, v, s);
+    if (rc != SNK_OK) return rc;
+    if (row_begin < 0 || row_end > v.n || row_begin > row_end) return snk_internal_fail(c, SNK_E_ARG, "row range out of bounds");
+    const size_t n = (size_t)v.n;
+    // in tiles, so that the job list stays small
+    const size_t tile_rows = std::max<size_t>(1, (size_t)(1u << 20) / n);
+    std::vector<DflJob> jobs;
+    for (size_t r0 = (size_t)row_begin; r0 < (size_t)row_end; r0 += tile_rows) {
+        const size_t r1 = std::min<size_t>((size_t)row_end, r0 + tile_rows);
+        jobs.resize((r1 - r0) * n);
+        for (size_t i = r0; i < r1; ++i)
+            for (size_t j = 0; j < n; ++j)
+                jobs[(i - r0) * n + j] = DflJob{(int32_t)i, (int32_t)j, 0u, (uint32_t)((i - r0) * n + j)};
+        rc = dfl_launch(c, s, v, level, jobs, sizes + (r0 - (size_t)row_begin) * n);
+        if (rc != SNK_OK) return rc;
+    }
+    return SNK_OK;
+}
+
+int snk_deflate_pairs_list(snk_ctx *c, int level, int n_pairs, const int32_t *ij, uint32_t *sizes)
+{
+    if (!c || n_pairs < 0 || (n_pairs > 0 && (!ij || !sizes))) return c ? snk_internal_fail(c, SNK_E_ARG, "bad arguments") : SNK_E_ARG;
+    SnkSeqView v; DflState *s = nullptr;
+    int rc = dfl_prepare(c, level, v, s);
+    if (rc != SNK_OK) return rc;
+    std::vector<DflJob> jobs((size_t)n_pairs);
+    for (int t = 0; t < n_pairs; ++t) {
+        const int32_t i = ij[2 * t], j = ij[2 * t + 1];
+        if (i < 0 || i >= v.n || j < -1 || j >= v.n) return snk_internal_fail(c, SNK_E_ARG, "pair index out of range");
+        jobs[(size_t)t] = DflJob{i, j, 0u, (uint32_t)t};
+    }
+    return dfl_launch(c, s, v, level, jobs, sizes);
+}
+
+}  // extern "C"

@@ -22,7 +22,12 @@ EXPORTS = (
     "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
+    "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list",
 )
+
+#: deflate level and wrapper bytes behind the reference's gzip / zlib choices
+#: (ref:snacc/pairwise_ncd.py:73-78: gzip.compress -> level 9 + 18 B, zlib.compress -> level 6 + 6 B)
+DEFLATE = {"gzip": (9, 18), "zlib": (6, 6)}
 
 
 class HipBackendError(RuntimeError):
@@ -109,6 +114,14 @@ def load():
     L.snk_free.argtypes = [vp]
     L.snk_upload_fasta.restype = i32
     L.snk_upload_fasta.argtypes = [vp, i32, vp, i32, i32]
+    L.snk_deflate_prepare.restype = i32
+    L.snk_deflate_prepare.argtypes = [vp, i32]
+    L.snk_deflate_singles.restype = i32
+    L.snk_deflate_singles.argtypes = [vp, i32, vp]
+    L.snk_deflate_pairs.restype = i32
+    L.snk_deflate_pairs.argtypes = [vp, i32, i32, i32, vp]
+    L.snk_deflate_pairs_list.restype = i32
+    L.snk_deflate_pairs_list.argtypes = [vp, i32, i32, vp, vp]
     if L.snk_version() != ABI_VERSION:
         raise HipBackendError(f"ABI mismatch: library {L.snk_version()}, binding {ABI_VERSION}")
     _lib = L
@@ -268,6 +281,28 @@ class HipContext:
         self._check(self._L.snk_frames_list(self._h, n, ij.ctypes.data, offsets.ctypes.data, out.ctypes.data),
                     "snk_frames_list")
         return [out[int(offsets[t]):int(offsets[t + 1])].tobytes() for t in range(n)]
+
+    # ---- gzip / zlib sizes (len(gzip.compress(..)) / len(zlib.compress(..)), wrapper included) ----
+    def deflate_singles(self, algorithm):
+        level, wrapper = DEFLATE[algorithm]
+        out = np.zeros(self.n, dtype=np.uint32)
+        self._check(self._L.snk_deflate_singles(self._h, level, out.ctypes.data), "snk_deflate_singles")
+        return out + np.uint32(wrapper)
+
+    def deflate_pairs(self, algorithm, row_begin=0, row_end=None):
+        level, wrapper = DEFLATE[algorithm]
+        row_end = self.n if row_end is None else row_end
+        out = np.zeros((row_end - row_begin, self.n), dtype=np.uint32)
+        self._check(self._L.snk_deflate_pairs(self._h, level, row_begin, row_end, out.ctypes.data), "snk_deflate_pairs")
+        return out + np.uint32(wrapper)
+
+    def deflate_pairs_list(self, algorithm, ij):
+        level, wrapper = DEFLATE[algorithm]
+        ij = np.ascontiguousarray(ij, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros(len(ij), dtype=np.uint32)
+        self._check(self._L.snk_deflate_pairs_list(self._h, level, len(ij), ij.ctypes.data, out.ctypes.data),
+                    "snk_deflate_pairs_list")
+        return out + np.uint32(wrapper)
 
     def sync(self, stream=None):
         self._check(self._L.snk_sync(self._h, ctypes.c_void_p(stream) if stream else None), "snk_sync")

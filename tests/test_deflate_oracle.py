@@ -1,0 +1,94 @@
+"""The deflate oracle (oracle/deflate_oracle.c) pinned against the real codec: the
+interpreter's own gzip / zlib modules (zlib 1.2.11 in this image), i.e. exactly what ref:snacc/pairwise_ncd.py:73-78
+calls.  CPU only."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+SAMPLE = b"ACTGACTAGCTAGCTAACTGGCATCGTAGCTAGCTACGATCATCGATCGTACGTACGTAGATCGATCGATCGTACGATCG"
+
+
+@pytest.fixture(scope="module")
+def D():
+    from oracle import deflate
+    deflate.lib()
+    return deflate
+
+
+def _gen(rng, kind, n):
+    if kind == 0:
+        return rng.choice(ACGT, n)
+    if kind == 1:
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == 2:
+        u = rng.choice(ACGT, int(rng.integers(1, 2000)))
+        a = np.tile(u, n // len(u) + 1)[:n].copy()
+        m = rng.random(n) < 0.01
+        a[m] = rng.choice(ACGT, int(m.sum()))
+        return a
+    if kind == 3:
+        return rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8), n)
+    if kind == 4:
+        return np.repeat(rng.choice(ACGT, n // 50 + 1), rng.integers(1, 100, n // 50 + 1))[:n].copy()
+    return rng.choice(np.frombuffer(b"AC", dtype=np.uint8), n)
+
+
+def test_reference_fixture_sizes(D):
+    # sizes of ref:test_dataset/sample.fa incl. sys.getsizeof's 33 (single / self pair)
+    assert D.gzip_size(SAMPLE) + 33 == 89 and D.gzip_size(SAMPLE, SAMPLE) + 33 == 92
+    assert D.zlib_size(SAMPLE) + 33 == 77 and D.zlib_size(SAMPLE, SAMPLE) + 33 == 80
+
+
+def test_empty_and_tiny(D):
+    for b in (b"", b"A", b"AC", b"ACG", b"ACGT", b"AAAAAAAAAA", bytes(range(256))):
+        assert D.gzip_size(b) == len(gzip.compress(b))
+        assert D.zlib_size(b) == len(zlib.compress(b))
+
+
+def test_differential_fuzz_against_the_zlib_binary(D):
+    rng = np.random.default_rng(20261003)
+    for it in range(90):
+        n = int(rng.integers(0, 150000)) if it % 3 else int(rng.integers(0, 300))
+        a = _gen(rng, it % 6, n)
+        b = bytes(a)
+        assert D.gzip_size(a) == len(gzip.compress(b)), (it, n)
+        assert D.zlib_size(a) == len(zlib.compress(b)), (it, n)
+
+
+def test_lengths_around_window_and_block_edges(D):
+    rng = np.random.default_rng(3)
+    for n in (32767, 32768, 32769, 65535, 65536, 65537, 65274, 65275, 65536 + 261, 65536 + 262, 98304, 98305, 131072):
+        for kind in (0, 2):
+            a = _gen(rng, kind, n)
+            assert D.gzip_size(a) == len(gzip.compress(bytes(a))), (n, kind)
+            assert D.zlib_size(a) == len(zlib.compress(bytes(a))), (n, kind)
+
+
+def test_pairs_are_concatenations(D, oracle_mod):
+    x, y = oracle_mod.lcg_genome(1, 120000), oracle_mod.lcg_genome(2, 90000)
+    b = bytes(x) + bytes(y)
+    assert D.gzip_size(x, y) == len(gzip.compress(b))
+    assert D.zlib_size(x, y) == len(zlib.compress(b))
+    assert D.gzip_size(x, np.zeros(0, np.uint8)) == D.gzip_size(x)
+
+
+def test_block_cost_function_matches_stream(D, oracle_mod):
+    # one block: its bits from dfl_oracle_block_bits (histogram only) == the traced block
+    x = oracle_mod.lcg_genome(5, 60000)
+    raw, sym, blk = D.trace(x, level=9)
+    first = sym[:16383]
+    lf = np.zeros(286, np.uint16); df = np.zeros(30, np.uint16)
+    for s in first:
+        s = int(s)
+        if s >> 31:
+            lc, dist = (s >> 16) & 0x7fff, (s & 0xffff) - 1
+            lcode = lc if lc < 8 else (28 if lc == 255 else 4 * (lc.bit_length() - 1) - 4 + ((lc >> (lc.bit_length() - 3)) & 3))
+            dcode = dist if dist < 4 else 2 * (dist.bit_length() - 1) + ((dist >> (dist.bit_length() - 2)) & 1)
+            lf[257 + lcode] += 1; df[dcode] += 1
+        else:
+            lf[s] += 1
+    assert D.block_bits(lf, df) == int(blk[0])
+    assert (int(blk.sum()) + 7) // 8 == raw

@@ -60,6 +60,20 @@ def one(seed):
              "anything": ["acgt", "acgtn", "soft", "bytes", "aa", "repeat", "mix"]}[profile]
     n = int(rng.integers(6, 15))
     seqs = [gen(rng, rand_len(rng), str(rng.choice(kinds))) for _ in range(n)]
+    # relatives: mutated / shifted / truncated copies of earlier members (long cross-seam matches)
+    for _ in range(int(rng.integers(0, 4))):
+        src = seqs[int(rng.integers(0, len(seqs)))]
+        if len(src) < 100:
+            continue
+        a = src.copy()
+        hit = rng.random(len(a)) < rng.choice([0.0, 0.0005, 0.01, 0.1])
+        a[hit] = rng.choice(ACGT, int(hit.sum()))
+        for _ in range(int(rng.integers(0, 4))):                    # indels
+            q = int(rng.integers(0, len(a)))
+            a = np.concatenate([a[:q], rng.choice(ACGT, int(rng.integers(0, 50))), a[q + int(rng.integers(0, 50)):]])
+        s0 = int(rng.integers(0, min(len(a) // 2, 70000) + 1))
+        seqs[int(rng.integers(0, len(seqs)))] = a[s0:]
+    n = len(seqs)
     exp_s = np.array([oracle.lz4f_size(x) for x in seqs], dtype=np.uint32)
     exp_p = pairs_mt(seqs, 0, n, 16)
     bad = []
