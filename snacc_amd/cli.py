@@ -106,9 +106,13 @@ def save_lz4_blobs(ctx, files, save_directory, rows=None):
 
 
 def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
-    """Phases A-C for ``-c lz4`` on the HIP backend.  Returns the float64 NCD matrix in `files`
-    order on rank 0 (None on other ranks)."""
-    from .hip_backend import HipContext
+    return gpu_matrix(files, "lz4", reverse_complement, show_progress, save_directory)
+
+
+def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directory=None):
+    """Phases A-C for ``-c lz4`` / ``gzip`` / ``zlib`` on the HIP backend.  Returns the float64 NCD
+    matrix in `files` order on rank 0 (None on other ranks)."""
+    from .hip_backend import HipContext, DEFLATE
 
     world, rank = _dist_env()
     click.secho("Compressing individual files...", fg="green")
@@ -118,9 +122,28 @@ def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
         # every file is parsed ONCE, by host threads inside the library, then
         # uploaded; phase A (singles + prefix snapshots) runs as part of the upload
         ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
-        singles = ctx.singles().astype(np.int64) + GETSIZEOF_OVERHEAD
+        deflate = algorithm in DEFLATE
+        singles = (ctx.deflate_singles(algorithm) if deflate else ctx.singles()).astype(np.int64) + GETSIZEOF_OVERHEAD
         click.secho("Compressing pairs...", fg="green")
-        if world > 1:
+        if deflate and world > 1:
+            import torch
+            import torch.distributed as dist
+            from .distributed import all_pairs_sharded
+            torch.cuda.set_device(ctx.device)
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device))
+            pairs = all_pairs_sharded(n, lambda r0, r1: ctx.deflate_pairs(algorithm, r0, r1),
+                                      device=torch.device("cuda", ctx.device)).astype(np.int64) + GETSIZEOF_OVERHEAD
+        elif deflate:
+            tile = max(1, (1 << 18) // max(n, 1))
+            starts = range(0, n, tile)
+            if show_progress and n > tile:
+                starts = tqdm(starts, total=(n + tile - 1) // tile)
+            pairs = (np.concatenate([ctx.deflate_pairs(algorithm, r0, min(n, r0 + tile)) for r0 in starts])
+                     if n else np.zeros((0, 0), np.uint32))
+            pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
+        elif world > 1:
             import torch
             import torch.distributed as dist
             from .distributed import all_pairs_hip
@@ -206,8 +229,12 @@ def cli(sequences, fasta, directories, numThreads, compression, showProgress, sa
 
     files = discover_files(sequences, fasta, directories)
 
-    if compression == "lz4":
-        matrix = lz4_matrix(files, reverse_complement, showProgress, saveCompression)
+    # gzip / zlib: on the HIP backend too unless the compressed files themselves are
+    # wanted (-s) or the reference's own thread-pool flow is asked for with SNACC_DEFLATE=stdlib
+    deflate_on_gpu = (compression in ("gzip", "zlib") and saveCompression is None
+                      and os.environ.get("SNACC_DEFLATE", "hip") != "stdlib")
+    if compression == "lz4" or deflate_on_gpu:
+        matrix = gpu_matrix(files, compression, reverse_complement, showProgress, saveCompression)
     else:
         matrix = threadpool_matrix(files, compression, numThreads, saveCompression, reverse_complement,
                                    showProgress)

@@ -7,9 +7,10 @@ Same three functions, same signatures and error behaviour:
 * :func:`compute_distance`   -- ref:snacc/pairwise_ncd.py:93-111
 
 ``algorithm == "lz4"`` goes to the HIP backend (``libsnacc_hip.so``) -- there is no CPU
-fallback for it.  The other codecs are the stdlib calls the reference makes (out of scope
-for the GPU).  :func:`all_pairs_lz4` is the batched entry the CLI uses
-instead of N*N single calls.
+fallback for it.  For the other codecs a single-item call is the stdlib call the reference
+makes.  :func:`all_pairs` is the batched entry the CLI uses instead of N*N single calls; it
+runs on the HIP backend for ``lz4``, ``gzip`` and ``zlib`` and has no CPU
+fallback either.
 """
 import bz2
 import gzip
@@ -108,28 +109,47 @@ def compute_distance(x, y, cxy, cyx):
         return min((cxy - x) / x, (cyx - x) / x)
 
 
-def all_pairs_lz4(sequences, ctx=None, rows=None):
-    """Batched phase A + B of ref:snacc/cli.py:108-129 for the lz4 codec.
+GPU_ALGORITHMS = ("lz4", "gzip", "zlib")
 
-    sequences: list of ``bytes``/``str`` (already extracted).  Returns ``(singles, pairs)`` as
-    int64 arrays *including* the getsizeof overhead; ``rows=(r0, r1)`` restricts phase B to a
+
+def all_pairs(sequences, algorithm="lz4", ctx=None, rows=None):
+    """Batched phase A + B of ref:snacc/cli.py:108-129 on the HIP backend.
+
+    sequences: list of ``bytes``/``str`` (already extracted); algorithm: ``lz4``, ``gzip`` or
+    ``zlib``.  Returns ``(singles, pairs)`` as int64 arrays *including* the getsizeof overhead
+    (and, for gzip / zlib, the 18 / 6 wrapper bytes); ``rows=(r0, r1)`` restricts phase B to a
     row range (multi-GPU sharding)."""
+    if algorithm not in GPU_ALGORITHMS:
+        raise KeyError(algorithm)
     own = ctx is None
     if own:
         from .hip_backend import HipContext
         ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")))
     try:
         ctx.upload(sequences)
-        singles = ctx.singles().astype(np.int64) + GETSIZEOF_OVERHEAD
         r0, r1 = rows if rows is not None else (0, len(sequences))
-        pairs = ctx.pairs(r0, r1).astype(np.int64) + GETSIZEOF_OVERHEAD
+        if algorithm == "lz4":
+            singles, pairs = ctx.singles(), ctx.pairs(r0, r1)
+        else:
+            singles, pairs = ctx.deflate_singles(algorithm), ctx.deflate_pairs(algorithm, r0, r1)
+        singles = singles.astype(np.int64) + GETSIZEOF_OVERHEAD
+        pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
     finally:
         if own:
             ctx.close()
     return singles, pairs
 
 
-def ncd_matrix_lz4(sequences, ctx=None):
-    """Full N x N NCD matrix (float64) for extracted sequences, lz4 codec, one GPU."""
-    singles, pairs = all_pairs_lz4(sequences, ctx=ctx)
+def all_pairs_lz4(sequences, ctx=None, rows=None):
+    """:func:`all_pairs` for the lz4 codec."""
+    return all_pairs(sequences, "lz4", ctx=ctx, rows=rows)
+
+
+def ncd_matrix_gpu(sequences, algorithm="lz4", ctx=None):
+    """Full N x N NCD matrix (float64) for extracted sequences on one GPU."""
+    singles, pairs = all_pairs(sequences, algorithm, ctx=ctx)
     return ncd_matrix(singles, pairs)
+
+
+def ncd_matrix_lz4(sequences, ctx=None):
+    return ncd_matrix_gpu(sequences, "lz4", ctx=ctx)

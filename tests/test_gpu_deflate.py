@@ -1,0 +1,149 @@
+"""GPU parity tests of the gzip / zlib path: the HIP backend, through the C-ABI,
+against the codec the reference calls (the interpreter's gzip / zlib, ref:snacc/pairwise_ncd.py:73-78)
+and against the deflate oracle.  Bit-exact sizes."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import materialise_cli_set
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+CODEC = {"gzip": gzip.compress, "zlib": zlib.compress}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from snacc_amd import hip_backend
+    hip_backend.load()
+    return hip_backend
+
+
+def _b(x):
+    return x if isinstance(x, (bytes, bytearray)) else bytes(np.ascontiguousarray(x, dtype=np.uint8))
+
+
+def _check_all_vs_codec(hip, seqs):
+    """singles and every ordered pair, both algorithms, against the real codec"""
+    raw = [_b(s) for s in seqs]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        for alg, fn in CODEC.items():
+            s, p = ctx.deflate_singles(alg), ctx.deflate_pairs(alg)
+            es = np.array([len(fn(a)) for a in raw], dtype=np.uint32)
+            ep = np.array([[len(fn(a + b)) for b in raw] for a in raw], dtype=np.uint32)
+            assert np.array_equal(s, es), (alg, np.flatnonzero(s != es))
+            assert np.array_equal(p, ep), (alg, np.argwhere(p != ep)[:5])
+
+
+def test_tiny_and_empty_inputs(hip):
+    _check_all_vs_codec(hip, [b"ACGT" * 10, b"ACGTTGCA" * 3, b"A", b"", b"ACGTN" * 5, b"GATTACA" * 1000, b"AC", b"ACG",
+                              b"ACGTACGTACGTA", bytes(range(256))])
+
+
+def test_lengths_around_window_slides_and_block_cuts(hip, oracle_mod):
+    lens = [32767, 32768, 32769, 65274, 65275, 65536, 65537, 65536 + 262, 98304, 131073, 600, 601, 33000]
+    _check_all_vs_codec(hip, [oracle_mod.lcg_genome(100 + i, n) for i, n in enumerate(lens)])
+
+
+def test_mixed_alphabets_stored_blocks_and_long_runs(hip, oracle_mod):
+    rng = np.random.default_rng(11)
+    seqs = [rng.integers(0, 256, 90000, dtype=np.uint8),                       # incompressible: stored blocks
+            rng.choice(ACGT, 120000),
+            np.tile(rng.choice(ACGT, 700), 200),                                 # period 700: matches of 258
+            np.full(100000, ord("A"), dtype=np.uint8),                           # one long run
+            rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8), 80000),
+            np.repeat(rng.choice(ACGT, 3000), 40)[:100000].copy(),               # homopolymer runs
+            np.concatenate([rng.integers(0, 256, 40000, dtype=np.uint8), rng.choice(ACGT, 70000)]),
+            rng.choice(np.frombuffer(b"AC", dtype=np.uint8), 70000)]
+    _check_all_vs_codec(hip, seqs)
+
+
+def test_related_genomes_and_tandem_repeats(hip, oracle_mod):
+    rng = np.random.default_rng(12)
+    x = oracle_mod.lcg_genome(7, 150000)
+    y = x.copy()
+    hit = rng.random(len(y)) < 0.02
+    y[hit] = rng.choice(ACGT, int(hit.sum()))
+    unit = rng.choice(ACGT, 1900)
+    t = np.tile(unit, 80)[:140000].copy()
+    hit = rng.random(len(t)) < 0.01
+    t[hit] = rng.choice(ACGT, int(hit.sum()))
+    _check_all_vs_codec(hip, [x, y, x[5000:], t, t[::-1].copy(), y[:70000]])
+
+
+def test_pair_lists_tiles_and_single_items(hip, oracle_mod):
+    seqs = [oracle_mod.lcg_genome(60 + i, 66000 + 7777 * i) for i in range(7)]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        for alg in ("gzip", "zlib"):
+            full = ctx.deflate_pairs(alg)
+            tiles = np.concatenate([ctx.deflate_pairs(alg, 0, 2), ctx.deflate_pairs(alg, 2, 7)])
+            assert np.array_equal(full, tiles)
+            ij = [(i, j) for i in range(7) for j in range(7)][::-1]
+            assert np.array_equal(ctx.deflate_pairs_list(alg, ij), full[::-1, ::-1].reshape(-1))
+            assert np.array_equal(ctx.deflate_pairs_list(alg, [(i, -1) for i in range(7)]), ctx.deflate_singles(alg))
+
+
+def test_1mbp_pairs_sample_against_the_oracle(hip, oracle_mod):
+    """BASELINE's 1 Mbp size: the full 12 x 12 matrices on the GPU, a sample of pairs against the CPU
+    oracle (about 2 s per gzip pair there), plus properties that need no oracle."""
+    from oracle import deflate as D
+    seqs = [oracle_mod.lcg_genome(1 + i, 1000000) for i in range(12)]
+    empty = np.zeros(0, dtype=np.uint8)
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs + [empty])
+        for alg, fn in (("gzip", D.gzip_size), ("zlib", D.zlib_size)):
+            s, p = ctx.deflate_singles(alg), ctx.deflate_pairs(alg)
+            assert np.array_equal(p[:12, 12], s[:12]) and np.array_equal(p[12, :12], s[:12])   # x + "" == x == "" + x
+            for i, j in ((0, 1), (1, 0), (3, 3), (11, 5)):
+                assert int(p[i, j]) == fn(seqs[i], seqs[j]), (alg, i, j)
+            assert int(s[4]) == fn(seqs[4])
+
+
+def test_python_batched_api_and_ncd(hip, oracle_mod):
+    from snacc_amd.pairwise_ncd import all_pairs, ncd_matrix_gpu, compute_distance
+    seqs = [bytes(oracle_mod.lcg_genome(30 + i, 40000 + 5000 * i)) for i in range(5)]
+    for alg, fn in CODEC.items():
+        singles, pairs = all_pairs(seqs, alg)
+        assert [int(v) for v in singles] == [len(fn(a)) + 33 for a in seqs]
+        m = ncd_matrix_gpu(seqs, alg)
+        for i in range(5):
+            for j in range(5):
+                exp = compute_distance(len(fn(seqs[i])) + 33, len(fn(seqs[j])) + 33,
+                                       len(fn(seqs[i] + seqs[j])) + 33, len(fn(seqs[j] + seqs[i])) + 33)
+                assert abs(m[i, j] - exp) <= 1e-6          # north_star's tolerance; equal integers give equal floats
+                assert m[i, j] == exp
+
+
+def test_cli_gzip_csv_equals_reference_cli(hip, golden, oracle_mod, tmp_path, monkeypatch):
+    """`snacc <dir> -c gzip` on the HIP backend writes the CSV the reference CLI wrote (golden fixture)."""
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    g = golden["cli_gzip"]
+    d = materialise_cli_set(oracle_mod, golden["cli_lz4"]["sets"][g["set"]], tmp_path / "fa")
+    out = tmp_path / "gz.csv"
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("SNACC_DEFLATE", raising=False)
+    res = CliRunner().invoke(cli, [str(d), "-o", str(out), "-c", "gzip", "--no-show-progress"])
+    assert res.exit_code == 0, res.output
+    assert res.output == g["stdout"]
+    assert out.read_text() == g["csv"].replace("{DIR}", str(d))
+
+
+def test_cli_zlib_equals_thread_pool_flow(hip, golden, oracle_mod, tmp_path, monkeypatch):
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    d = materialise_cli_set(oracle_mod, golden["cli_lz4"]["sets"]["acgt_small"], tmp_path / "fa")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("SNACC_DEFLATE", raising=False)
+    a = CliRunner().invoke(cli, [str(d), "-o", "gpu.csv", "-c", "zlib", "-r", "--no-show-progress", "--no-log"])
+    monkeypatch.setenv("SNACC_DEFLATE", "stdlib")
+    b = CliRunner().invoke(cli, [str(d), "-o", "cpu.csv", "-c", "zlib", "-r", "-n", "4", "--no-show-progress", "--no-log"])
+    assert a.exit_code == 0 and b.exit_code == 0, (a.output, b.output)
+    assert (tmp_path / "gpu.csv").read_text() == (tmp_path / "cpu.csv").read_text()

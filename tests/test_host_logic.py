@@ -157,6 +157,7 @@ def test_cli_gzip_flow_matches_reference_cli(golden, oracle_mod, tmp_path, monke
     d = materialise_cli_set(oracle_mod, spec, tmp_path / "fa")
     out = tmp_path / "gz.csv"
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SNACC_DEFLATE", "stdlib")        # the reference's own thread-pool flow, asked for explicitly
     res = CliRunner().invoke(cli, [str(d), "-o", str(out), "-c", "gzip", "-n", "2", "--no-show-progress"])
     assert res.exit_code == 0, res.output
     assert res.output == g["stdout"]
@@ -175,7 +176,27 @@ def test_cli_deprecated_flags_warn_and_work(tmp_path, monkeypatch):
     (d / "a.fa").write_text(">a\nACGTACGTAC\n")
     (d / "b.fa").write_text(">b\nACGTACGTTT\n")
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SNACC_DEFLATE", "stdlib")
     res = CliRunner().invoke(cli, ["-d", str(d), "-f", str(d / "a.fa"), "-o", "o.csv", "-c", "zlib", "--no-show-progress", "--no-log"])
     assert res.exit_code == 0, res.output
     assert "deprecated" in res.output
     assert len((tmp_path / "o.csv").read_text().splitlines()) == 3
+
+
+def test_cli_gzip_defaults_to_the_hip_backend_and_fails_loudly_without_it(tmp_path, monkeypatch):
+    """`-c gzip` / `-c zlib` run on the HIP backend; without a device they fail, they do
+    not quietly fall back to the CPU codec."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    from click.testing import CliRunner
+    from snacc_amd.cli import cli
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "a.fa").write_text(">a\nACGTACGTAC\n")
+    (d / "b.fa").write_text(">b\nACGTACGTTT\n")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("SNACC_DEFLATE", raising=False)
+    res = CliRunner().invoke(cli, [str(d), "-o", "o.csv", "-c", "gzip", "--no-show-progress", "--no-log"])
+    assert res.exit_code != 0
+    assert not (tmp_path / "o.csv").exists()
