@@ -75,7 +75,9 @@ struct DflJob { int32_t xi, yi; uint32_t standalone, out_idx; };
 struct DflTables {
     const uint8_t *bytes;
     DflSeq *seq;
-    const uint32_t *occ, *inv, *bstart;      // bstart: 32769 entries per sequence
+    const uint32_t *occ, *bstart;            // bstart: 32769 entries per sequence
+    const uint64_t *occ8;                    // the 8 sequence bytes at occ[i] (coalesced candidate compares)
+    const uint64_t *inv2;                    // per position: index in occ (low 32) | rank in its bucket (high 32)
     uint32_t *sym, *pos;
     uint64_t *cumbits;
     uint32_t *rhist;                         // 320 counters per sequence: open block at the restart point
@@ -108,11 +110,18 @@ __global__ void dfl_bstart_kernel(const uint16_t *skey, uint32_t m, uint32_t *bs
     bstart[h] = lo;
 }
 
-__global__ void dfl_inv_kernel(const uint32_t *occ, uint32_t m, uint32_t *inv)
+// inv2[p] = (index of p in occ) | (rank of p inside its hash bucket) << 32;  occ8[i] = the 8 bytes at occ[i]
+__global__ void dfl_inv_kernel(const uint32_t *occ, const uint16_t *skey, const uint32_t *bstart, const uint8_t *b,
+                               uint32_t m, uint64_t *inv2, uint64_t *occ8)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (; i < m; i += stride) inv[occ[i]] = i;
+    for (; i < m; i += stride) {
+        const uint32_t p = occ[i];
+        inv2[p] = (uint64_t)i | ((uint64_t)(i - bstart[skey[i]]) << 32);
+        struct __attribute__((packed)) U64 { uint64_t v; };
+        occ8[i] = ((const U64 *)(b + p))->v;               // the arena is zero padded behind every sequence
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,8 +361,16 @@ __device__ __forceinline__ uint32_t dfl_window_base(uint32_t p0, uint32_t n)
 // ---------------------------------------------------------------------------------------------
 // one parse job per wavefront
 // ---------------------------------------------------------------------------------------------
+#ifdef DFL_STAMP
+__device__ unsigned long long dfl_stamp_buf[64 * 8];
+#define DFL_T(v) v = clock64()
+#else
+#define DFL_T(v) do { } while (0)
+#endif
+
 struct DflWave {
     DflLds L;
+    unsigned long long t_flush;
     uint32_t lane;
     // block accounting
     uint64_t bits;
@@ -377,6 +394,8 @@ __device__ __forceinline__ void dfl_hist_reset(DflWave &w)
 // Close the open block: p0 = loop top of the iteration that closes it, end = strstart at that moment.
 __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
 {
+    unsigned long long tf0 = 0, tf1 = 0; (void)tf0; (void)tf1;
+    DFL_T(tf0);
     if (w.lane == 0) {
         long opt_len, static_len;
         dfl_block_lengths(w.L, opt_len, static_len);
@@ -411,6 +430,8 @@ __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
     __builtin_amdgcn_wave_barrier();
     w.bcount = 0;
     w.block_start = end;
+    DFL_T(tf1);
+    w.t_flush += tf1 - tf0;
 }
 
 // One symbol from the parser (wave-uniform arguments).  is_match: len/dist valid.
@@ -441,7 +462,8 @@ __global__ void __launch_bounds__(64 * DFL_WAVES)
 dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
     extern __shared__ __align__(16) uint8_t dfl_lds[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // the wave index is uniform: telling the compiler so moves the whole parser state to SGPRs
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t jid = blockIdx.x * DFL_WAVES + wave;
     if (jid >= njobs) return;
     const DflJob job = jobs[jid];
@@ -462,8 +484,10 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     S.Y = pair ? T.bytes + sy.boff : S.X; S.ly = pair ? sy.len : 0u;
     S.n = S.lx + S.ly;
     const uint32_t lx = S.lx, n = S.n;
-    const uint32_t *occx = T.occ + sx.ioff, *invx = T.inv + sx.ioff, *bsx = T.bstart + (size_t)job.xi * (DFL_NHASH + 1u);
-    const uint32_t *occy = T.occ + sy.ioff, *invy = T.inv + sy.ioff, *bsy = T.bstart + (size_t)(pair ? job.yi : job.xi) * (DFL_NHASH + 1u);
+    const uint32_t *occx = T.occ + sx.ioff, *bsx = T.bstart + (size_t)job.xi * (DFL_NHASH + 1u);
+    const uint32_t *occy = T.occ + sy.ioff;
+    const uint64_t *occ8x = T.occ8 + sx.ioff, *occ8y = T.occ8 + sy.ioff;
+    const uint64_t *inv2x = T.inv2 + sx.ioff, *inv2y = T.inv2 + sy.ioff;
 
     // the two seam positions whose 3-byte hash mixes x and y
     const bool has1 = pair && lx >= 1u && lx - 1u + 3u <= n;
@@ -471,7 +495,10 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     const uint32_t hs1 = has1 ? dfl_hash3(S, lx - 1u) : 0xFFFFFFFFu;
     const uint32_t hs2 = has2 ? dfl_hash3(S, lx - 2u) : 0xFFFFFFFFu;
 
-    w.n = n; w.unsafe = 0; w.nblk = 0;
+    w.n = n; w.unsafe = 0; w.nblk = 0; w.t_flush = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, acc_search = 0, acc_sync = 0, iters = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)ta; (void)tb; (void)acc_search; (void)acc_sync; (void)iters;
+    DFL_T(t0);
     w.store = job.standalone != 0u;
     w.sym = T.sym + sx.soff; w.pos = T.pos + sx.soff; w.cumbits = T.cumbits + sx.coff;
 
@@ -503,18 +530,23 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
         const uint32_t la = n - p;
         const uint32_t prev_length = match_length, prev_match = match_start;
         match_length = 2u;
+        DFL_T(ta); iters++;
         if (la >= 3u && prev_length < T.lazy) {
             // ---- the chain of p: earlier positions with the same hash, most recent first ----
-            const uint32_t h = dfl_hash3(S, p);
+            const uint64_t s0 = dfl_load8(S, p);                 // la >= 3: its first three bytes are input
+            const uint32_t h = ((((uint32_t)s0 & 0xffu) << 10) ^ ((((uint32_t)s0 >> 8) & 0xffu) << 5) ^
+                                (((uint32_t)s0 >> 16) & 0xffu)) & 0x7fffu;
             uint32_t ny = 0, ybase = 0, nsp = 0, sp0 = 0, sp1 = 0, nx = 0, xtop = 0;
             if (p >= lx) {
-                const uint32_t r = invy[p - lx] - bsy[h];
-                ny = r; ybase = bsy[h] + r - 1u;
+                const uint64_t e = inv2y[p - lx];
+                ny = (uint32_t)(e >> 32); ybase = (uint32_t)e - 1u;
                 if (hs1 == h) { sp0 = lx - 1u; nsp = 1u; }
                 if (hs2 == h) { if (nsp) sp1 = lx - 2u; else sp0 = lx - 2u; nsp++; }
-                if (pair) { nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u; }
+                // x's bucket is needed only while the chain can still reach the seam
+                if (pair && p - lx <= DFL_MAX_DIST) { nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u; }
             } else if (p + 3u <= lx) {
-                nx = invx[p] - bsx[h]; xtop = bsx[h] + nx - 1u;
+                const uint64_t e = inv2x[p];
+                nx = (uint32_t)(e >> 32); xtop = (uint32_t)e - 1u;
             } else {
                 if (p == lx - 1u && hs2 == h) { sp0 = lx - 2u; nsp = 1u; }
                 nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u;
@@ -526,45 +558,77 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
                 const uint32_t nice = T.nice > la ? la : T.nice;
                 const uint32_t lim = total < chain ? total : chain;
                 uint32_t best_len = prev_length;
-                bool first = true;
-                for (uint32_t j0 = 0; j0 < lim; j0 += 64u) {
-                    const uint32_t j = j0 + lane;
-                    uint32_t q = 0;
-                    bool valid = j < lim;
-                    if (valid) {
-                        if (j < ny) q = lx + occy[ybase - j];
-                        else if (j - ny < nsp) q = (j - ny) == 0u ? sp0 : sp1;
-                        else q = occx[xtop - (j - ny - nsp)];
-                        const uint32_t dist = p - q;
-                        valid = q != 0u && dist <= (j == 0u ? DFL_MAX_DIST : DFL_MAX_DIST - 1u);
+                bool searched = false, done = false;
+                // 256 candidates per step, four per lane, their loads in flight together.  Every lane
+                // gets the byte-exact common length within the first 8 bytes; the groups of 64 are then
+                // walked in chain order by "first lane that beats the best so far" (one ballot per round,
+                // each round raises the best length) -- zlib's own update rule.
+                for (uint32_t j0 = 0; j0 < lim && !done; j0 += 256u) {
+                    uint32_t q[4], len8[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t j = j0 + 64u * (uint32_t)u + lane;
+                        const bool in = j < lim;
+                        const bool fromy = j < ny;
+                        const bool special = !fromy && j - ny < nsp;
+                        uint32_t v = 0;
+                        uint64_t d8 = 0;
+                        if (in && !special) {                    // position and its 8 bytes: two coalesced reads
+                            const uint32_t idx = fromy ? ybase - j : xtop - (j - ny - nsp);
+                            v = (fromy ? occy : occx)[idx];
+                            d8 = (fromy ? occ8y : occ8x)[idx];
+                        }
+                        q[u] = fromy ? lx + v : (special ? (j == ny ? sp0 : sp1) : v);
+                        ok[u] = in && q[u] != 0u && p - q[u] <= (j == 0u ? DFL_MAX_DIST : DFL_MAX_DIST - 1u);
+                        // the stored bytes are the stream's only if they do not run over their sequence's end
+                        const bool whole = !special && v + 8u <= (fromy ? S.ly : lx);
+                        uint64_t x8 = d8 ^ s0;
+                        if (ok[u] && !whole) x8 = dfl_load8(S, q[u]) ^ s0;
+                        len8[u] = x8 ? (uint32_t)__builtin_ctzll(x8) >> 3 : 8u;
                     }
-                    // the walk ends at the first candidate that is out of range
-                    const uint64_t bad = __builtin_amdgcn_ballot_w64(!valid);
-                    const uint32_t nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
-                    if (first && nvalid == 0u) break;             // hash_head unusable: no search at all
-                    first = false;
-                    const bool act = lane < nvalid;
-                    const uint32_t len = act ? dfl_lcp(S, p, q) : 0u;
-                    // zlib stops at the first candidate that improves on the best so far and reaches nice_match
-                    const uint32_t need = nice > best_len + 1u ? nice : best_len + 1u;
-                    const uint64_t hit = __builtin_amdgcn_ballot_w64(act && len >= need);
-                    const uint32_t upto = hit ? (uint32_t)__builtin_ctzll(hit) + 1u : nvalid;
-                    uint32_t m = lane < upto ? len : 0u;
-                    for (uint32_t o = 32u; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, (int)o, 64); m = t > m ? t : m; }
-                    if (m > best_len) {
-                        const uint64_t who = __builtin_amdgcn_ballot_w64(lane < upto && len == m);
-                        const uint32_t src = (uint32_t)__builtin_ctzll(who);
-                        match_start = (uint32_t)__shfl((int)q, (int)src, 64);
-                        best_len = m;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (done || j0 + 64u * (uint32_t)u >= lim) break;
+                        // the walk ends at the first candidate that is out of range
+                        const uint64_t bad = __builtin_amdgcn_ballot_w64(!ok[u]);
+                        const uint32_t nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                        if (!searched && nvalid == 0u) { done = true; break; }   // hash_head unusable: no search at all
+                        searched = true;
+                        const uint64_t live = nvalid < 64u ? (1ull << nvalid) - 1ull : ~0ull;
+                        uint64_t after = ~0ull;                   // lanes behind the last one looked at
+                        for (;;) {
+                            const uint32_t floor8 = best_len < 7u ? best_len : 7u;
+                            const uint64_t cand = __builtin_amdgcn_ballot_w64(len8[u] > floor8) & live & after;
+                            if (!cand) break;
+                            const uint32_t i = (uint32_t)__builtin_ctzll(cand);
+                            after = i < 63u ? ~((2ull << i) - 1ull) : 0ull;
+                            uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)len8[u], (int)i);
+                            const uint32_t qi = (uint32_t)__builtin_amdgcn_readlane((int)q[u], (int)i);
+                            if (len == 8u) {                      // 8 equal bytes: keep comparing (uniform addresses)
+                                while (len < DFL_MAX_MATCH) {
+                                    const uint64_t y8 = dfl_load8(S, p + len) ^ dfl_load8(S, qi + len);
+                                    if (y8) { len += (uint32_t)__builtin_ctzll(y8) >> 3; break; }
+                                    len += 8u;
+                                }
+                                if (len > DFL_MAX_MATCH) len = DFL_MAX_MATCH;
+                            }
+                            if (len > best_len) {
+                                best_len = len;
+                                match_start = qi;
+                                if (len >= nice) { done = true; break; }
+                            }
+                        }
+                        if (nvalid < 64u) done = true;
                     }
-                    if (hit || nvalid < 64u) break;
                 }
-                if (!first) {
+                if (searched) {
                     match_length = best_len <= la ? best_len : la;
                     if (match_length == 3u && p - match_start > DFL_TOO_FAR) match_length = 2u;
                 }
             }
         }
+        DFL_T(tb); acc_search += tb - ta;
         if (prev_length >= 3u && match_length <= prev_length) {
             const uint32_t q = p - 1u;
             dfl_emit(w, true, q, 0u, prev_length, q - prev_match);
@@ -574,8 +638,10 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
             // both parsers right behind a match, and x out of reach: from here on y's own stream
             if (try_sync && p >= lx + DFL_MAX_DIST + 1u && p < n) {
                 const uint32_t want = p - lx;
+                DFL_T(ta);
                 uint32_t lo = 0, hi = sy.nsym;                   // first k with posy[k] >= want
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (posy[mid] < want) lo = mid + 1u; else hi = mid; }
+                DFL_T(tb); acc_sync += tb - ta;
                 if (lo < sy.nsym && lo > 0u && posy[lo] == want && (symy[lo - 1u] >> 31)) { sync_k = lo; break; }
             }
         } else if (match_available) {
@@ -587,6 +653,8 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
         }
     }
 
+    DFL_T(t1);
+    const unsigned long long flush_parse = w.t_flush;
     if (sync_k != 0xFFFFFFFFu) {
         // ---- y's own symbols from sync_k on, re-cut into this stream's blocks ----
         uint32_t k = sync_k;
@@ -619,7 +687,15 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
         dfl_emit(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
     }
     __builtin_amdgcn_wave_barrier();
+    DFL_T(t2);
     dfl_flush(w, true, n, n);
+    DFL_T(t3);
+#ifdef DFL_STAMP
+    if (lane == 0 && jid < 64u) {
+        unsigned long long *d = dfl_stamp_buf + jid * 8u;
+        d[0] = t1 - t0; d[1] = acc_search; d[2] = acc_sync; d[3] = flush_parse; d[4] = t2 - t1; d[5] = w.t_flush - flush_parse; d[6] = iters; d[7] = t3 - t0;
+    }
+#endif
 
     if (lane == 0) {
         out[job.out_idx] = (uint32_t)(w.bits >> 3);
@@ -683,7 +759,8 @@ struct DflState {
     bool indexed = false;
     std::vector<DflSeq> seq;
     DflSeq *d_seq = nullptr;
-    uint32_t *d_occ = nullptr, *d_inv = nullptr, *d_bstart = nullptr;
+    uint32_t *d_occ = nullptr, *d_bstart = nullptr;
+    uint64_t *d_occ8 = nullptr, *d_inv2 = nullptr;
     uint32_t *d_sym = nullptr, *d_pos = nullptr, *d_rhist = nullptr, *d_status = nullptr;
     uint64_t *d_cumbits = nullptr;
     DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
@@ -698,7 +775,7 @@ void dfl_destroy(void *v)
     DflState *s = (DflState *)v;
     if (!s) return;
     (void)hipSetDevice(s->device);
-    dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_inv); dfree(s->d_bstart); dfree(s->d_sym); dfree(s->d_pos);
+    dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart); dfree(s->d_sym); dfree(s->d_pos);
     dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
     delete s;
 }
@@ -723,7 +800,7 @@ bool level_config(int level, DflTables &T)
 DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
 {
     DflTables T{};
-    T.bytes = v.d_bytes; T.seq = s->d_seq; T.occ = s->d_occ; T.inv = s->d_inv; T.bstart = s->d_bstart;
+    T.bytes = v.d_bytes; T.seq = s->d_seq; T.occ = s->d_occ; T.occ8 = s->d_occ8; T.inv2 = s->d_inv2; T.bstart = s->d_bstart;
     T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
     level_config(level, T);
     return T;
@@ -795,7 +872,8 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
     }
     DCHK(c, hipMalloc((void **)&s->d_seq, n * sizeof(DflSeq)));
     DCHK(c, hipMalloc((void **)&s->d_occ, itot * 4));
-    DCHK(c, hipMalloc((void **)&s->d_inv, itot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_occ8, itot * 8));
+    DCHK(c, hipMalloc((void **)&s->d_inv2, itot * 8));
     DCHK(c, hipMalloc((void **)&s->d_bstart, n * (DFL_NHASH + 1u) * 4));
     DCHK(c, hipMalloc((void **)&s->d_sym, stot * 4));
     DCHK(c, hipMalloc((void **)&s->d_pos, stot * 4));
@@ -803,7 +881,7 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
     DCHK(c, hipMalloc((void **)&s->d_rhist, n * DFL_HIST * 4));
     DCHK(c, hipMalloc((void **)&s->d_status, 4));
     DCHK(c, hipMemsetAsync(s->d_status, 0, 4, v.stream));
-    DCHK(c, hipMemsetAsync(s->d_inv, 0, itot * 4, v.stream));
+    DCHK(c, hipMemsetAsync(s->d_inv2, 0, itot * 8, v.stream));
 
     uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
     const size_t cap = (size_t)maxlen + 1u;
@@ -824,9 +902,13 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
             hipLaunchKernelGGL(dfl_hash_kernel, dim3(grid), dim3(256), 0, v.stream, v.d_bytes + q.boff, m, d_key, d_val);
             hipError_t e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_skey, d_val, s->d_occ + q.ioff, (int)m, 0, 15, v.stream);
             if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort failed");
-            hipLaunchKernelGGL(dfl_inv_kernel, dim3(grid), dim3(256), 0, v.stream, s->d_occ + q.ioff, m, s->d_inv + q.ioff);
         }
         hipLaunchKernelGGL(dfl_bstart_kernel, dim3((DFL_NHASH + 1u + 255u) / 256u), dim3(256), 0, v.stream, d_skey, m, bst);
+        if (m) {
+            const uint32_t grid = std::min<uint32_t>((m + 255u) / 256u, 4096u);
+            hipLaunchKernelGGL(dfl_inv_kernel, dim3(grid), dim3(256), 0, v.stream, s->d_occ + q.ioff, d_skey, bst,
+                               v.d_bytes + q.boff, m, s->d_inv2 + q.ioff, s->d_occ8 + q.ioff);
+        }
     }
     DCHK(c, hipGetLastError());
     DCHK(c, hipStreamSynchronize(v.stream));
@@ -865,6 +947,13 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
 }  // namespace
 
 extern "C" {
+
+#ifdef DFL_STAMP
+int snk_debug_dfl_stamps(unsigned long long *out /* [64*8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dfl_stamp_buf), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int snk_deflate_prepare(snk_ctx *c, int level)
 {
