@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- all-pairs lz4 NCD hot path on MI355X (BASELINE.json metric).
+"""bench.py -- all-pairs NCD hot path on MI355X (BASELINE.json metric; lz4 by default).
 
 One "step" = one pass of the hot path over one batch: the frame sizes of
 ``rows_per_step x N`` ordered genome pairs (a tile of rows of the N x N matrix
@@ -8,6 +8,9 @@ followed -- when more than one rank runs -- by the RCCL all-gather of the tile.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+``--codec gzip|zlib`` measures the deflate path the same way; the default and
+the headline metric is lz4.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 The oracle (oracle/) is used only by the ``cpu_baseline`` leg and a spot parity
@@ -73,6 +76,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="extra backend option key=value (repeatable)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--codec", choices=["lz4", "gzip", "zlib"], default="lz4")
     args = ap.parse_args()
 
     import torch
@@ -120,6 +124,9 @@ def main():
     ctx = HipContext(local_rank, **opts)
     t0 = time.time()
     ctx.upload(genomes)                                  # H2D + classify + pack + singles/snapshots (untimed)
+    deflate = args.codec != "lz4"
+    if deflate:
+        ctx.deflate_singles(args.codec)                  # match index + every sequence's own symbol stream (untimed)
     t_upload = time.time() - t0
 
     # row shard of this rank (weak scaling: every rank does R rows per step from its own shard)
@@ -145,9 +152,19 @@ def main():
         else:
             dist.all_gather_into_tensor(gathered, tile)
 
+    kern_ms = []
+
+    def launch(r0):
+        if deflate:                                      # blocking call, sizes returned to the host
+            host = ctx.deflate_pairs(args.codec, r0, r0 + R) - np.uint32({"gzip": 18, "zlib": 6}[args.codec])
+            kern_ms.append(ctx.deflate_last_ms())
+            tile.copy_(torch.from_numpy(host.view(np.int32)), non_blocking=False)
+        else:
+            ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+
     def step(k):
         r0 = shard0 + (k * R) % max(rows_per_rank - R + 1, 1)
-        ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+        launch(r0)
         gather()
         return r0
 
@@ -160,6 +177,7 @@ def main():
         step(k)
     fence()
     ctx.sync(stream.cuda_stream)
+    kern_ms.clear()
 
     # HIP events on the stream the kernels are launched on (torch's current stream is passed to the
     # C-ABI).  One pair around the whole timed region: per-launch pairs under-report back-to-back
@@ -171,7 +189,7 @@ def main():
     ev_begin.record(stream)
     for k in range(args.steps):
         r0 = shard0 + ((args.warmup + k) * R) % max(rows_per_rank - R + 1, 1)
-        ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+        launch(r0)
         gather()
         last_r0 = r0
     ev_end.record(stream)
@@ -190,6 +208,8 @@ def main():
     # late on this ROCm build, so the region pair is kept only as a cross-check.
     kern_ms_region = ev_begin.elapsed_time(ev_end) / args.steps
     kern_ms_avg = lib_last_ms if lib_last_ms > 0 else kern_ms_region
+    if deflate:
+        kern_ms_avg = float(np.mean(kern_ms))
 
     pairs_per_step = R * N * world
     pair_rate = pairs_per_step * args.steps / elapsed
@@ -212,8 +232,45 @@ def main():
         from oracle.loader import pairs_mt
         host_tile = tile.cpu().numpy().view(np.uint32)
         js = [0, 1, N // 2, N - 1]
-        parity = all(int(host_tile[0, j]) == oracle.lz4f_size_pair(genomes[last_r0], genomes[j]) for j in js)
-        if not args.no_cpu_baseline and world == 1:
+        if deflate:
+            from oracle import deflate as dfl_oracle
+            lvl = {"gzip": 9, "zlib": 6}[args.codec]
+            parity = all(int(host_tile[0, j]) == dfl_oracle.raw_size(genomes[last_r0], genomes[j], lvl) for j in js[:2])
+        else:
+            parity = all(int(host_tile[0, j]) == oracle.lz4f_size_pair(genomes[last_r0], genomes[j]) for j in js)
+        if deflate and not args.no_cpu_baseline and world == 1:
+            # the codec the reference itself calls (stdlib gzip / zlib, GIL released), one thread per core
+            import gzip as _gzip
+            import zlib as _zlib
+            fn = {"gzip": _gzip.compress, "zlib": _zlib.compress}[args.codec]
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            raw = [bytes(g) for g in genomes[:min(N, 64)]]
+            budget_s = 20.0                              # bounded sample: every thread compresses pairs until the deadline
+            import threading
+            counts = [0] * cores
+            t0 = time.perf_counter()
+
+            def work(t):
+                i = t
+                while time.perf_counter() - t0 < budget_s and (not args.cpu_sample_pairs or counts[t] * cores < args.cpu_sample_pairs):
+                    fn(raw[i % len(raw)] + raw[(7 * i + 1) % len(raw)])
+                    counts[t] += 1
+                    i += cores
+
+            threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            dt = time.perf_counter() - t0
+            npairs = sum(counts)
+            cpu_baseline = {
+                "value": npairs / dt / 2.0, "unit": "NCD/s", "cores": cores, "kind": "reference",
+                "pair_compressions_per_s": npairs / dt,
+                "sample": f"{npairs} ordered pairs of {L} bp genomes, {args.codec}.compress of the interpreter "
+                          f"(zlib {_zlib.ZLIB_RUNTIME_VERSION}), {cores} threads, {dt:.1f} s wall",
+            }
+        elif not args.no_cpu_baseline and world == 1:
             cores = os.cpu_count() or 1
             per_pair_s = 8.3e-3 * (2 * L / 2e6)           # survey probe: 8.3 ms per 2 Mbp pair per core
             want = args.cpu_sample_pairs or int(max(cores, min(20.0 / max(per_pair_s, 1e-6), 4096)))
@@ -232,20 +289,20 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "genome-pair NCDs/sec (lz4, all ordered pairs; 1 NCD = 2 pair-compressions)",
+            "metric": f"genome-pair NCDs/sec ({args.codec}, all ordered pairs; 1 NCD = 2 pair-compressions)",
             "value": ncd_rate, "unit": "NCD/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (LCG uniform ACGT, seed = 1 + genome index)",
-            "config": {"workload": f"{N} synthetic {L} bp genomes, lz4, rows_per_step={R} x {N} cols per GPU",
+            "config": {"workload": f"{N} synthetic {L} bp genomes, {args.codec}, rows_per_step={R} x {N} cols per GPU",
                        "genomes": N, "length": L, "rows_per_step_per_gpu": R,
                        "parallelism": f"row-shard x{world}" + (" + RCCL all-gather" if world > 1 else "")},
             "pair_compressions_per_s": pair_rate,
             "matrix_wall_s_est": (N * N + N) / pair_rate,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic_bytes(R, N, L),
-                         "kernel": "snk_fast_kernel" if not args.force_generic else "snk_generic_kernel",
+                         "frac": achieved / 8000.0, "traffic": None if deflate else pmc_traffic_bytes(R, N, L),
+                         "kernel": "dfl_parse_kernel" if deflate else ("snk_fast_kernel" if not args.force_generic else "snk_generic_kernel"),
                          "kernel_ms_avg": kern_ms_avg, "kernel_ms_region_torch_events": kern_ms_region,
                          "alg_bytes_per_launch": alg_bytes_launch},
             "cpu_baseline": cpu_baseline,

@@ -153,6 +153,8 @@ int snk_deflate_prepare(snk_ctx *ctx, int level);
 int snk_deflate_singles(snk_ctx *ctx, int level, uint32_t *sizes /* [n_seq], host */);
 int snk_deflate_pairs(snk_ctx *ctx, int level, int row_begin, int row_end, uint32_t *sizes /* host */);
 int snk_deflate_pairs_list(snk_ctx *ctx, int level, int n_pairs, const int32_t *ij, uint32_t *sizes /* host */);
+/* Device time (ms) of the kernels of the last snk_deflate_pairs / snk_deflate_pairs_list call; < 0 if unavailable. */
+double snk_deflate_last_ms(snk_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -766,6 +766,8 @@ struct DflState {
     DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
     uint32_t *d_out = nullptr; size_t out_cap = 0;
     std::vector<uint32_t> single;        // raw stream bytes of every sequence at `level`
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = -1.0;               // device time of the parse kernels of the last pairs call
 };
 
 template <typename P> void dfree(P *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
@@ -777,6 +779,8 @@ void dfl_destroy(void *v)
     (void)hipSetDevice(s->device);
     dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart); dfree(s->d_sym); dfree(s->d_pos);
     dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
 }
 
@@ -846,13 +850,18 @@ int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const st
     DCHK(c, hipMemcpyAsync(s->d_jobs, jobs.data(), jobs.size() * sizeof(DflJob), hipMemcpyHostToDevice, v.stream));
     const DflTables T = make_tables(s, v, level);
     const uint32_t nj = (uint32_t)jobs.size();
+    if (!s->ev0) { DCHK(c, hipEventCreate(&s->ev0)); DCHK(c, hipEventCreate(&s->ev1)); }
+    DCHK(c, hipEventRecord(s->ev0, v.stream));
     hipLaunchKernelGGL(dfl_parse_kernel, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
                        v.stream, T, s->d_jobs, nj, s->d_out);
     DCHK(c, hipGetLastError());
+    DCHK(c, hipEventRecord(s->ev1, v.stream));
     if (host_out) {
         DCHK(c, hipMemcpyAsync(host_out, s->d_out, jobs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
     }
     DCHK(c, hipStreamSynchronize(v.stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = (s->last_ms < 0 ? 0.0 : s->last_ms) + (double)ms;
     return SNK_OK;
 }
 
@@ -980,6 +989,7 @@ int snk_deflate_pairs(snk_ctx *c, int level, int row_begin, int row_end, uint32_
     if (rc != SNK_OK) return rc;
     if (row_begin < 0 || row_end > v.n || row_begin > row_end) return snk_internal_fail(c, SNK_E_ARG, "row range out of bounds");
     const size_t n = (size_t)v.n;
+    s->last_ms = -1.0;
     // in tiles, so that the job list stays small
     const size_t tile_rows = std::max<size_t>(1, (size_t)(1u << 20) / n);
     std::vector<DflJob> jobs;
@@ -1001,6 +1011,7 @@ int snk_deflate_pairs_list(snk_ctx *c, int level, int n_pairs, const int32_t *ij
     SnkSeqView v; DflState *s = nullptr;
     int rc = dfl_prepare(c, level, v, s);
     if (rc != SNK_OK) return rc;
+    s->last_ms = -1.0;
     std::vector<DflJob> jobs((size_t)n_pairs);
     for (int t = 0; t < n_pairs; ++t) {
         const int32_t i = ij[2 * t], j = ij[2 * t + 1];
@@ -1008,6 +1019,15 @@ int snk_deflate_pairs_list(snk_ctx *c, int level, int n_pairs, const int32_t *ij
         jobs[(size_t)t] = DflJob{i, j, 0u, (uint32_t)t};
     }
     return dfl_launch(c, s, v, level, jobs, sizes);
+}
+
+/* Device time (ms, hipEvent pair around the parse kernels) of the last snk_deflate_pairs /
+ * snk_deflate_pairs_list call; < 0 if unavailable. */
+double snk_deflate_last_ms(snk_ctx *c)
+{
+    if (!c) return -1.0;
+    void **slot = snk_internal_dfl_slot(c, nullptr);
+    return *slot ? ((DflState *)*slot)->last_ms : -1.0;
 }
 
 }  // extern "C"
