@@ -69,6 +69,8 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   resident sequences use <= 2048 distinct 5-byte hashes (set before upload)
  *   "bytes_legacy"  1 = linked-mode byte jobs use the legacy u32-table kernel (testing)
  *   "force_generic" 1 = route every pair through the byte kernel (testing)
+ *   "deflate_serial" 1 = gzip / zlib: parse every single sequence with one wavefront from start to end
+ *                   instead of in stitched parallel segments (testing; set before the first deflate call)
  *   "content_size"  1 = add the 8-byte content-size field to every frame
  *                   (py-lz4framed builds that set it)        */
 int snk_set_option(snk_ctx *ctx, const char *key, long value);

@@ -70,7 +70,12 @@ struct DflSeq {              // one per resident sequence (device + host mirror)
     uint32_t rkb, rbpos;     // first symbol / stream position of the block that is open at rk
 };
 
-struct DflJob { int32_t xi, yi; uint32_t standalone, out_idx; };
+// mode 0: pair (or single, yi = -1) size from the stored streams;  1: whole sequence, serial (stores its stream,
+// prices it);  2: segment [p0, p1) of a sequence into the scratch stream at `aux` (no pricing);  3: price the
+// stored stream of a sequence
+struct DflJob { int32_t xi, yi; uint32_t mode, out_idx; uint32_t p0, p1; uint64_t aux; };
+constexpr uint32_t DFL_SEG = 32768u;           // segment length of the parallel per-sequence pass
+constexpr uint32_t DFL_SEG_SLACK = 2048u;      // a segment runs this far into the next one, for the stitch
 
 struct DflTables {
     const uint8_t *bytes;
@@ -81,6 +86,7 @@ struct DflTables {
     uint32_t *sym, *pos;
     uint64_t *cumbits;
     uint32_t *rhist;                         // 320 counters per sequence: open block at the restart point
+    uint32_t *seg_sym, *seg_pos, *seg_cnt;   // scratch streams of the segment jobs, and their symbol counts
     uint32_t good, lazy, nice, chain;
     uint32_t *status;
 };
@@ -380,6 +386,8 @@ struct DflWave {
     uint32_t unsafe;
     // output of the stand-alone stream
     bool store;
+    bool price;               // cut into blocks and price them
+    bool keep_blocks;
     uint32_t *sym, *pos;
     uint64_t *cumbits;
     uint32_t nsym;
@@ -423,7 +431,7 @@ __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
         w.bits += 3ull + val;
     }
     if (last) w.bits = (w.bits + 7ull) & ~7ull;
-    if (w.store && w.lane == 0) w.cumbits[w.nblk] = w.bits;
+    if (w.keep_blocks && w.lane == 0) w.cumbits[w.nblk] = w.bits;
     w.nblk++;
     __builtin_amdgcn_wave_barrier();
     dfl_hist_reset(w);
@@ -438,11 +446,13 @@ __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
 __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, uint32_t lit, uint32_t len, uint32_t dist, bool tail = false)
 {
     if (w.lane == 0) {
-        if (is_match) {
-            w.L.hist[257u + dfl_lcode(len - 3u)]++;
-            w.L.hist[DFL_DOFF + dfl_dcode(dist - 1u)]++;
-        } else {
-            w.L.hist[lit]++;
+        if (w.price) {
+            if (is_match) {
+                w.L.hist[257u + dfl_lcode(len - 3u)]++;
+                w.L.hist[DFL_DOFF + dfl_dcode(dist - 1u)]++;
+            } else {
+                w.L.hist[lit]++;
+            }
         }
         if (w.store) {
             w.sym[w.nsym] = is_match ? (0x80000000u | ((len - 3u) << 16) | dist) : lit;
@@ -452,7 +462,7 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
     w.nsym++;
     w.bcount++;
     // (the literal zlib tallies after its main loop never closes a block: the final flush does)
-    if (w.bcount == DFL_BLOCK_SYMS && !tail) {
+    if (w.price && w.bcount == DFL_BLOCK_SYMS && !tail) {
         __builtin_amdgcn_wave_barrier();
         dfl_flush(w, false, q + 1u, is_match ? q + len : q + 1u);
     }
@@ -499,11 +509,16 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, acc_search = 0, acc_sync = 0, iters = 0;
     (void)t0; (void)t1; (void)t2; (void)t3; (void)ta; (void)tb; (void)acc_search; (void)acc_sync; (void)iters;
     DFL_T(t0);
-    w.store = job.standalone != 0u;
+    const uint32_t mode = job.mode;
+    w.store = mode == 1u || mode == 2u;
+    w.price = mode != 2u;
     w.sym = T.sym + sx.soff; w.pos = T.pos + sx.soff; w.cumbits = T.cumbits + sx.coff;
+    if (mode == 2u) { w.sym = T.seg_sym + job.aux; w.pos = T.seg_pos + job.aux; }
+    const bool keep_blocks = mode == 1u || mode == 3u;          // record the bit count after every block
 
+    w.keep_blocks = keep_blocks;
     uint32_t p;
-    const bool restart = !w.store && sx.unsafe == 0u && sx.rk != 0u;
+    const bool restart = mode == 0u && sx.unsafe == 0u && sx.rk != 0u;
     if (restart) {
         for (uint32_t i = lane; i < DFL_HIST; i += 64u) w.L.hist[i] = T.rhist[(size_t)job.xi * DFL_HIST + i];
         const uint32_t blocks_before = sx.rkb / DFL_BLOCK_SYMS;
@@ -516,12 +531,17 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     } else {
         dfl_hist_reset(w);
         w.bits = 0; w.bcount = 0; w.nsym = 0; w.block_start = 0; p = 0;
+        if (mode == 2u) p = job.p0;                              // a segment starts as if right behind a match
+        if (mode == 3u) p = n;                                   // nothing to parse: the stream is stored
     }
     __builtin_amdgcn_wave_barrier();
 
-    const bool try_sync = pair && !w.store && S.ly > 65536u && sy.nsym != 0u;
+    const bool try_sync = mode == 0u && pair && S.ly > 65536u && sy.nsym != 0u;
     const uint32_t *symy = T.sym + sy.soff, *posy = T.pos + sy.soff;
-    uint32_t sync_k = 0xFFFFFFFFu;
+    uint32_t sync_k = mode == 3u ? 0u : 0xFFFFFFFFu;              // pricing = "synchronised" with the own stream at symbol 0
+    const uint32_t seg_stop = (mode == 2u && job.p1 < n) ? job.p1 + DFL_SEG_SLACK : 0xFFFFFFFFu;
+    const uint32_t yoff = mode == 3u ? 0u : lx;                  // stream position of the streamed symbols' base
+    const uint32_t ynsym = sy.nsym;
 
     uint32_t match_length = 2u, match_start = 0u;
     bool match_available = false;
@@ -635,6 +655,7 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
             p = q + prev_length;
             match_available = false;
             match_length = 2u;
+            if (p >= seg_stop) break;                             // segment: far enough into the next one
             // both parsers right behind a match, and x out of reach: from here on y's own stream
             if (try_sync && p >= lx + DFL_MAX_DIST + 1u && p < n) {
                 const uint32_t want = p - lx;
@@ -659,8 +680,8 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
         // ---- y's own symbols from sync_k on, re-cut into this stream's blocks ----
         uint32_t k = sync_k;
         __builtin_amdgcn_wave_barrier();
-        while (k < sy.nsym) {
-            uint32_t m = sy.nsym - k;
+        while (k < ynsym) {
+            uint32_t m = ynsym - k;
             if (m > 64u) m = 64u;
             if (m > DFL_BLOCK_SYMS - w.bcount) m = DFL_BLOCK_SYMS - w.bcount;
             uint32_t s = 0;
@@ -676,19 +697,19 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
             k += m; w.bcount += m; w.nsym += m;
             if (w.bcount == DFL_BLOCK_SYMS) {
                 const uint32_t sl = (uint32_t)__shfl((int)s, (int)(m - 1u), 64);
-                const uint32_t q = lx + posy[k - 1u];
+                const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();
                 dfl_flush(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u);
             }
         }
         __builtin_amdgcn_wave_barrier();
-    } else if (match_available) {
+    } else if (match_available && p >= n) {
         dfl_emit(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
     }
     __builtin_amdgcn_wave_barrier();
     DFL_T(t2);
-    dfl_flush(w, true, n, n);
+    if (w.price) dfl_flush(w, true, n, n);
     DFL_T(t3);
 #ifdef DFL_STAMP
     if (lane == 0 && jid < 64u) {
@@ -698,12 +719,16 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 #endif
 
     if (lane == 0) {
-        out[job.out_idx] = (uint32_t)(w.bits >> 3);
-        if (w.store) {
-            DflSeq *d = T.seq + job.xi;
-            d->nsym = w.nsym - 0u;
-            d->unsafe = w.unsafe;
-            d->total_bits = w.bits;
+        if (mode == 2u) {
+            T.seg_cnt[job.out_idx] = w.nsym;
+        } else {
+            out[job.out_idx] = (uint32_t)(w.bits >> 3);
+            if (mode != 0u) {
+                DflSeq *d = T.seq + job.xi;
+                d->nsym = w.nsym;
+                d->unsafe = w.unsafe;
+                d->total_bits = w.bits;
+            }
         }
     }
 }
@@ -749,6 +774,54 @@ __global__ void __launch_bounds__(64) dfl_restart_kernel(DflTables T, uint32_t n
     }
 }
 
+// Stitch of the segment streams of one sequence.  Segment t starts at p0[t] "as if right behind a
+// match"; the stream of segment t-1 (which ran DFL_SEG_SLACK further) is the true one there.  From the
+// first position at which BOTH stand right behind a match the two parsers are in the same state
+// (state = position, the chains are data) and segment t's stream is the true continuation.
+// One thread per segment; ends[t] = symbols of t-1 that are kept, from[t] = first kept symbol of t.
+struct DflSeg { uint64_t aux; uint32_t p0, p1, first, cnt; };   // first: 1 = first segment of its sequence
+
+__global__ void dfl_stitch_kernel(const DflSeg *seg, const uint32_t *cnt, uint32_t nseg, const uint32_t *ssym,
+                                  const uint32_t *spos, uint32_t *from, uint32_t *ends, uint32_t *fail)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseg) return;
+    if (seg[t].first) { from[t] = 0u; return; }
+    const uint32_t *symA = ssym + seg[t - 1u].aux, *posA = spos + seg[t - 1u].aux;
+    const uint32_t *symB = ssym + seg[t].aux, *posB = spos + seg[t].aux;
+    const uint32_t cntA = cnt[t - 1u], cntB = cnt[t], s0 = seg[t].p0;
+    uint32_t lo = 0, hi = cntA;                               // first a with posA[a] >= s0
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (posA[mid] < s0) lo = mid + 1u; else hi = mid; }
+    uint32_t a = lo, b = 0;
+    // where A's stream ends (it stops right behind a match unless it ran to the end of the sequence)
+    uint32_t endA = 0;
+    if (cntA) { const uint32_t sl = symA[cntA - 1u]; endA = posA[cntA - 1u] + ((sl >> 31) ? ((sl >> 16) & 0x7fffu) + 3u : 1u); }
+    bool found = false;
+    while (b < cntB) {
+        const uint32_t pb = posB[b];
+        const bool cleanB = b == 0u || (symB[b - 1u] >> 31);
+        while (a < cntA && posA[a] < pb) a++;
+        if (a < cntA) {
+            if (posA[a] == pb && cleanB && a > 0u && (symA[a - 1u] >> 31)) { found = true; break; }
+        } else {
+            if (pb == endA && cleanB && cntA && (symA[cntA - 1u] >> 31)) { found = true; break; }
+            if (pb > endA) break;
+        }
+        b++;
+    }
+    if (found) { ends[t - 1u] = a; from[t] = b; }
+    else { ends[t - 1u] = 0u; from[t] = 0u; atomicOr(fail + t, 1u); }
+}
+
+__global__ void dfl_compact_kernel(const DflSeg *seg, const uint32_t *from, const uint32_t *num, const uint64_t *dst,
+                                   const uint32_t *ssym, const uint32_t *spos, uint32_t *sym, uint32_t *pos)
+{
+    const uint32_t t = blockIdx.x;
+    const uint32_t *a = ssym + seg[t].aux + from[t], *b = spos + seg[t].aux + from[t];
+    uint32_t *da = sym + dst[t], *db = pos + dst[t];
+    for (uint32_t i = threadIdx.x; i < num[t]; i += blockDim.x) { da[i] = a[i]; db[i] = b[i]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -766,6 +839,8 @@ struct DflState {
     DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
     uint32_t *d_out = nullptr; size_t out_cap = 0;
     std::vector<uint32_t> single;        // raw stream bytes of every sequence at `level`
+    uint32_t *d_seg_sym = nullptr, *d_seg_pos = nullptr, *d_seg_cnt = nullptr;   // scratch of the per-sequence pass
+    int n_serial = 0;                     // sequences of the last per-sequence pass that needed the serial parse
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = -1.0;               // device time of the parse kernels of the last pairs call
 };
@@ -779,6 +854,7 @@ void dfl_destroy(void *v)
     (void)hipSetDevice(s->device);
     dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart); dfree(s->d_sym); dfree(s->d_pos);
     dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
+    dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -806,6 +882,7 @@ DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
     DflTables T{};
     T.bytes = v.d_bytes; T.seq = s->d_seq; T.occ = s->d_occ; T.occ8 = s->d_occ8; T.inv2 = s->d_inv2; T.bstart = s->d_bstart;
     T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
+    T.seg_sym = s->d_seg_sym; T.seg_pos = s->d_seg_pos; T.seg_cnt = s->d_seg_cnt;
     level_config(level, T);
     return T;
 }
@@ -939,16 +1016,99 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     // stand-alone stream of every sequence at this level
     for (auto &q : s->seq) { q.nsym = 0; q.unsafe = 0; q.total_bits = 0; q.rk = q.rpos = q.rkb = q.rbpos = 0; }
     DCHK(c, hipMemcpy(s->d_seq, s->seq.data(), s->seq.size() * sizeof(DflSeq), hipMemcpyHostToDevice));
-    std::vector<DflJob> jobs((size_t)v.n);
-    for (int g = 0; g < v.n; ++g) jobs[(size_t)g] = DflJob{g, -1, 1u, (uint32_t)g};
     s->single.assign((size_t)v.n, 0u);
-    rc = dfl_launch(c, s, v, level, jobs, s->single.data());
-    if (rc != SNK_OK) return rc;
+    std::vector<int> serial;                 // sequences parsed by one wave from start to end
+    if (v.dfl_serial) {
+        for (int g = 0; g < v.n; ++g) serial.push_back(g);
+    } else {
+        // ---- in parallel segments, stitched where two parsers provably agree (dfl_stitch_kernel) ----
+        std::vector<DflSeg> segs;
+        std::vector<int> seg_seq;
+        uint64_t aux = 0;
+        for (int g = 0; g < v.n; ++g) {
+            const uint32_t len = v.len[g];
+            const uint32_t k = std::max<uint32_t>(1u, (len + DFL_SEG - 1u) / DFL_SEG);
+            for (uint32_t i = 0; i < k; ++i) {
+                DflSeg sg{};
+                sg.p0 = i * DFL_SEG; sg.p1 = std::min<uint64_t>((uint64_t)(i + 1u) * DFL_SEG, len);
+                sg.first = i == 0u; sg.aux = aux; sg.cnt = 0;
+                aux += (uint64_t)(sg.p1 - sg.p0) + DFL_SEG_SLACK + 300u;
+                segs.push_back(sg); seg_seq.push_back(g);
+            }
+        }
+        const size_t ns = segs.size();
+        dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt);
+        DCHK(c, hipMalloc((void **)&s->d_seg_sym, aux * 4));
+        DCHK(c, hipMalloc((void **)&s->d_seg_pos, aux * 4));
+        DCHK(c, hipMalloc((void **)&s->d_seg_cnt, ns * 4));
+        DflSeg *d_segs = nullptr; uint32_t *d_from = nullptr, *d_ends = nullptr, *d_fail = nullptr, *d_num = nullptr; uint64_t *d_dst = nullptr;
+        DCHK(c, hipMalloc((void **)&d_segs, ns * sizeof(DflSeg)));
+        DCHK(c, hipMalloc((void **)&d_from, ns * 4)); DCHK(c, hipMalloc((void **)&d_ends, ns * 4));
+        DCHK(c, hipMalloc((void **)&d_fail, ns * 4)); DCHK(c, hipMalloc((void **)&d_num, ns * 4));
+        DCHK(c, hipMalloc((void **)&d_dst, ns * 8));
+        DCHK(c, hipMemcpy(d_segs, segs.data(), ns * sizeof(DflSeg), hipMemcpyHostToDevice));
+        DCHK(c, hipMemset(d_fail, 0, ns * 4));
+        std::vector<DflJob> jobs(ns);
+        for (size_t t = 0; t < ns; ++t) jobs[t] = DflJob{seg_seq[t], -1, 2u, (uint32_t)t, segs[t].p0, segs[t].p1, segs[t].aux};
+        rc = dfl_launch(c, s, v, level, jobs, nullptr);
+        if (rc != SNK_OK) return rc;
+        hipLaunchKernelGGL(dfl_stitch_kernel, dim3((uint32_t)((ns + 63) / 64)), dim3(64), 0, v.stream, d_segs, s->d_seg_cnt,
+                           (uint32_t)ns, s->d_seg_sym, s->d_seg_pos, d_from, d_ends, d_fail);
+        DCHK(c, hipGetLastError());
+        std::vector<uint32_t> cnt(ns), from(ns), ends(ns), failv(ns), num(ns, 0u);
+        std::vector<uint64_t> dst(ns, 0ull);
+        DCHK(c, hipMemcpyAsync(cnt.data(), s->d_seg_cnt, ns * 4, hipMemcpyDeviceToHost, v.stream));
+        DCHK(c, hipMemcpyAsync(from.data(), d_from, ns * 4, hipMemcpyDeviceToHost, v.stream));
+        DCHK(c, hipMemcpyAsync(ends.data(), d_ends, ns * 4, hipMemcpyDeviceToHost, v.stream));
+        DCHK(c, hipMemcpyAsync(failv.data(), d_fail, ns * 4, hipMemcpyDeviceToHost, v.stream));
+        DCHK(c, hipStreamSynchronize(v.stream));
+        std::vector<DflJob> price;
+        for (size_t t = 0; t < ns;) {
+            const int g = seg_seq[t];
+            size_t e = t;
+            while (e < ns && seg_seq[e] == g) ++e;
+            bool ok = true;
+            uint64_t total = 0;
+            for (size_t u = t; u < e && ok; ++u) {
+                const uint32_t hi = u + 1 < e ? ends[u] : cnt[u];      // the last segment keeps everything to its end
+                if (failv[u] || hi < from[u]) { ok = false; break; }
+                num[u] = hi - from[u]; dst[u] = s->seq[(size_t)g].soff + total; total += num[u];
+            }
+            if (ok && total <= (uint64_t)v.len[g] + 1u) {
+                s->seq[(size_t)g].nsym = (uint32_t)total;
+                price.push_back(DflJob{g, -1, 3u, (uint32_t)price.size(), 0u, 0u, 0ull});
+            } else {
+                for (size_t u = t; u < e; ++u) num[u] = 0;
+                serial.push_back(g);                                   // e.g. periodic data whose parsers never meet
+            }
+            t = e;
+        }
+        DCHK(c, hipMemcpy(d_num, num.data(), ns * 4, hipMemcpyHostToDevice));
+        DCHK(c, hipMemcpy(d_dst, dst.data(), ns * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(dfl_compact_kernel, dim3((uint32_t)ns), dim3(256), 0, v.stream, d_segs, d_from, d_num, d_dst,
+                           s->d_seg_sym, s->d_seg_pos, s->d_sym, s->d_pos);
+        DCHK(c, hipGetLastError());
+        DCHK(c, hipMemcpyAsync(s->d_seq, s->seq.data(), s->seq.size() * sizeof(DflSeq), hipMemcpyHostToDevice, v.stream));
+        DCHK(c, hipStreamSynchronize(v.stream));
+        std::vector<uint32_t> sizes(price.size());
+        rc = dfl_launch(c, s, v, level, price, sizes.data());        // out_idx = sequence index: sized below
+        if (rc != SNK_OK) return rc;
+        dfree(d_segs); dfree(d_from); dfree(d_ends); dfree(d_fail); dfree(d_num); dfree(d_dst);
+        dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt);
+        s->n_serial = (int)serial.size();
+    }
+    if (!serial.empty()) {
+        std::vector<DflJob> jobs(serial.size());
+        for (size_t t = 0; t < serial.size(); ++t) jobs[t] = DflJob{serial[t], -1, 1u, (uint32_t)t, 0u, 0u, 0ull};
+        rc = dfl_launch(c, s, v, level, jobs, nullptr);
+        if (rc != SNK_OK) return rc;
+    }
     const DflTables T = make_tables(s, v, level);
     hipLaunchKernelGGL(dfl_restart_kernel, dim3((uint32_t)v.n), dim3(64), 0, v.stream, T, (uint32_t)v.n);
     DCHK(c, hipGetLastError());
     DCHK(c, hipStreamSynchronize(v.stream));
     DCHK(c, hipMemcpy(s->seq.data(), s->d_seq, s->seq.size() * sizeof(DflSeq), hipMemcpyDeviceToHost));
+    for (int g = 0; g < v.n; ++g) s->single[(size_t)g] = (uint32_t)(s->seq[(size_t)g].total_bits >> 3);
     s->level = level;
     return SNK_OK;
 }
@@ -998,7 +1158,7 @@ int snk_deflate_pairs(snk_ctx *c, int level, int row_begin, int row_end, uint32_
         jobs.resize((r1 - r0) * n);
         for (size_t i = r0; i < r1; ++i)
             for (size_t j = 0; j < n; ++j)
-                jobs[(i - r0) * n + j] = DflJob{(int32_t)i, (int32_t)j, 0u, (uint32_t)((i - r0) * n + j)};
+                jobs[(i - r0) * n + j] = DflJob{(int32_t)i, (int32_t)j, 0u, (uint32_t)((i - r0) * n + j), 0u, 0u, 0ull};
         rc = dfl_launch(c, s, v, level, jobs, sizes + (r0 - (size_t)row_begin) * n);
         if (rc != SNK_OK) return rc;
     }
@@ -1016,7 +1176,7 @@ int snk_deflate_pairs_list(snk_ctx *c, int level, int n_pairs, const int32_t *ij
     for (int t = 0; t < n_pairs; ++t) {
         const int32_t i = ij[2 * t], j = ij[2 * t + 1];
         if (i < 0 || i >= v.n || j < -1 || j >= v.n) return snk_internal_fail(c, SNK_E_ARG, "pair index out of range");
-        jobs[(size_t)t] = DflJob{i, j, 0u, (uint32_t)t};
+        jobs[(size_t)t] = DflJob{i, j, 0u, (uint32_t)t, 0u, 0u, 0ull};
     }
     return dfl_launch(c, s, v, level, jobs, sizes);
 }
