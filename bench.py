@@ -47,11 +47,11 @@ def lcg_genomes_torch(n_genomes, length, seed0, device):
     return out
 
 
-def pmc_traffic_bytes(rows, n, length):
+def pmc_traffic_bytes(rows, n, length, codec="lz4"):
     """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_pmc_traffic.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE doubled per the gfx950
     calibration of MI355X_MICROARCH.md).  Only valid for the launch shape it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if codec == "lz4" else f"r01_pmc_traffic_{codec}.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -301,7 +301,7 @@ def main():
             "pair_compressions_per_s": pair_rate,
             "matrix_wall_s_est": (N * N + N) / pair_rate,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None if deflate else pmc_traffic_bytes(R, N, L),
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic_bytes(R, N, L, args.codec),
                          "kernel": "dfl_parse_kernel" if deflate else ("snk_fast_kernel" if not args.force_generic else "snk_generic_kernel"),
                          "kernel_ms_avg": kern_ms_avg, "kernel_ms_region_torch_events": kern_ms_region,
                          "alg_bytes_per_launch": alg_bytes_launch},

@@ -77,6 +77,31 @@ def test_related_genomes_and_tandem_repeats(hip, oracle_mod):
     _check_all_vs_codec(hip, [x, y, x[5000:], t, t[::-1].copy(), y[:70000]])
 
 
+def test_segmented_and_serial_sequence_passes_agree(hip, oracle_mod):
+    """Every single sequence is parsed in parallel 32 KiB segments that are stitched where two parsers
+    provably agree; `deflate_serial=1` parses it with one wavefront from start to end.  Same sizes, for
+    random genomes (many segments), periodic data (parsers that may never meet: serial fallback) and runs."""
+    rng = np.random.default_rng(21)
+    t = np.tile(rng.choice(ACGT, 1900), 140)[:250000].copy()
+    hit = rng.random(len(t)) < 0.01
+    t[hit] = rng.choice(ACGT, int(hit.sum()))
+    seqs = [oracle_mod.lcg_genome(70, 300001), oracle_mod.lcg_genome(71, 2500000), np.tile(oracle_mod.lcg_genome(72, 1000), 400),
+            np.full(200000, ord("A"), dtype=np.uint8), t, rng.integers(0, 256, 150000, dtype=np.uint8),
+            np.tile(np.frombuffer(b"ACGTTGCA", dtype=np.uint8), 30000)]
+    raw = [_b(x) for x in seqs]
+    with hip.HipContext(0) as a, hip.HipContext(0, deflate_serial=1) as b:
+        a.upload(seqs)
+        b.upload(seqs)
+        for alg, fn in CODEC.items():
+            sa, sb = a.deflate_singles(alg), b.deflate_singles(alg)
+            assert np.array_equal(sa, sb), alg
+            assert [int(v) for v in sa] == [len(fn(x)) for x in raw], alg
+            pa, pb = a.deflate_pairs(alg), b.deflate_pairs(alg)
+            assert np.array_equal(pa, pb), alg
+            for i, j in ((0, 1), (1, 0), (2, 3), (3, 2), (4, 4), (5, 6), (6, 0)):
+                assert int(pa[i, j]) == len(fn(raw[i] + raw[j])), (alg, i, j)
+
+
 def test_pair_lists_tiles_and_single_items(hip, oracle_mod):
     seqs = [oracle_mod.lcg_genome(60 + i, 66000 + 7777 * i) for i in range(7)]
     with hip.HipContext(0) as ctx:
