@@ -83,6 +83,11 @@ struct DflTables {
     const uint32_t *occ, *bstart;            // bstart: 32769 entries per sequence
     const uint64_t *occ8;                    // the 8 sequence bytes at occ[i] (coalesced candidate compares)
     const uint64_t *inv2;                    // per position: index in occ (low 32) | rank in its bucket (high 32)
+    // second index, bucketed by a 16-bit hash of SIX bytes (positions <= len - 6): every chain member that
+    // matches the probe in >= 6 bytes is in the probe's bucket
+    const uint32_t *k_occ, *k_r3, *k_bstart;  // position, its rank in the 3-byte bucket; k_bstart: 65537 per sequence
+    const uint64_t *k_occ8, *k_inv2;          // the 8 bytes there; per position: index in k_occ | rank in its bucket
+    uint32_t use_k;
     uint32_t *sym, *pos;
     uint64_t *cumbits;
     uint32_t *rhist;                         // 320 counters per sequence: open block at the restart point
@@ -127,6 +132,42 @@ __global__ void dfl_inv_kernel(const uint32_t *occ, const uint16_t *skey, const 
         inv2[p] = (uint64_t)i | ((uint64_t)(i - bstart[skey[i]]) << 32);
         struct __attribute__((packed)) U64 { uint64_t v; };
         occ8[i] = ((const U64 *)(b + p))->v;               // the arena is zero padded behind every sequence
+    }
+}
+
+__host__ __device__ __forceinline__ uint32_t dfl_hash6(uint64_t v8)     // 16-bit hash of the low 6 bytes
+{
+    return (uint32_t)(((v8 & 0xFFFFFFFFFFFFull) * 0x9E3779B97F4A7C15ull) >> 48);
+}
+
+__global__ void dfl_khash_kernel(const uint8_t *b, uint32_t m, uint16_t *key, uint32_t *val)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    struct __attribute__((packed)) U64 { uint64_t v; };
+    for (; p < m; p += stride) { key[p] = (uint16_t)dfl_hash6(((const U64 *)(b + p))->v); val[p] = p; }
+}
+
+__global__ void dfl_kbstart_kernel(const uint16_t *skey, uint32_t m, uint32_t *bstart)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > 65536u) return;
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)skey[mid] < h) lo = mid + 1; else hi = mid; }
+    bstart[h] = lo;
+}
+
+__global__ void dfl_kinv_kernel(const uint32_t *kocc, const uint16_t *skey, const uint32_t *kbstart, const uint8_t *b,
+                                const uint64_t *inv2, uint32_t m, uint64_t *kinv2, uint64_t *kocc8, uint32_t *kr3)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    struct __attribute__((packed)) U64 { uint64_t v; };
+    for (; i < m; i += stride) {
+        const uint32_t p = kocc[i];
+        kinv2[p] = (uint64_t)i | ((uint64_t)(i - kbstart[skey[i]]) << 32);
+        kocc8[i] = ((const U64 *)(b + p))->v;
+        kr3[i] = (uint32_t)(inv2[p] >> 32);
     }
 }
 
@@ -468,7 +509,9 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
     }
 }
 
-__global__ void __launch_bounds__(64 * DFL_WAVES)
+// USE_K: with the six-byte index in the match search (level 9)
+template <bool USE_K>
+__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(5)))
 dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
     extern __shared__ __align__(16) uint8_t dfl_lds[];
@@ -498,12 +541,22 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     const uint32_t *occy = T.occ + sy.ioff;
     const uint64_t *occ8x = T.occ8 + sx.ioff, *occ8y = T.occ8 + sy.ioff;
     const uint64_t *inv2x = T.inv2 + sx.ioff, *inv2y = T.inv2 + sy.ioff;
+    const uint32_t *kbsx = T.k_bstart + (size_t)job.xi * 65537u;
+    const uint32_t *koccx = T.k_occ + sx.ioff, *koccy = T.k_occ + sy.ioff, *kr3x = T.k_r3 + sx.ioff, *kr3y = T.k_r3 + sy.ioff;
+    const uint64_t *kocc8x = T.k_occ8 + sx.ioff, *kocc8y = T.k_occ8 + sy.ioff;
+    const uint64_t *kinv2x = T.k_inv2 + sx.ioff, *kinv2y = T.k_inv2 + sy.ioff;
 
     // the two seam positions whose 3-byte hash mixes x and y
     const bool has1 = pair && lx >= 1u && lx - 1u + 3u <= n;
     const bool has2 = pair && lx >= 2u && lx - 2u + 3u <= n;
     const uint32_t hs1 = has1 ? dfl_hash3(S, lx - 1u) : 0xFFFFFFFFu;
     const uint32_t hs2 = has2 ? dfl_hash3(S, lx - 2u) : 0xFFFFFFFFu;
+    // the (up to) five seam positions whose six bytes mix x and y are in neither sequence's six-byte index:
+    // a probe whose hash equals one of theirs takes the full chain walk instead
+    uint32_t ks[5];
+#pragma unroll
+    for (uint32_t i = 0; i < 5u; ++i)
+        ks[i] = (pair && lx >= i + 1u && lx - (i + 1u) + 6u <= n) ? dfl_hash6(dfl_load8(S, lx - (i + 1u))) : 0xFFFFFFFFu;
 
     w.n = n; w.unsafe = 0; w.nblk = 0; w.t_flush = 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, acc_search = 0, acc_sync = 0, iters = 0;
@@ -572,13 +625,99 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
                 nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u;
             }
             const uint32_t total = ny + nsp + nx;
-            if (total != 0u) {
-                uint32_t chain = T.chain;
-                if (prev_length >= T.good) chain >>= 2;
-                const uint32_t nice = T.nice > la ? la : T.nice;
+            uint32_t chain = T.chain;
+            if (prev_length >= T.good) chain >>= 2;
+            const uint32_t nice = T.nice > la ? la : T.nice;
+            uint32_t best_len = prev_length;
+            bool searched = false, done = false;
+
+            // ---- K-pass: only the chain members that share the probe's six-byte hash.  If it finds a match of
+            // >= 6 bytes, that is what the full walk would return (the first longest member, or the first
+            // that reaches nice_match, has >= 6 matching bytes, hence sits in this bucket; members are taken
+            // in the same order, with their exact position j3 in the 3-byte chain for budget and head rule).
+            bool kdone = false;
+            const uint32_t match_start_in = match_start;
+            if (USE_K && total != 0u && la >= DFL_MIN_LOOKAHEAD && (p >= lx || p + 6u <= lx)) {
+                const uint32_t h6 = dfl_hash6(s0);
+                const bool kspecial = pair && p + 5u >= lx && p <= lx + DFL_MAX_DIST + 5u &&
+                                      (h6 == ks[0] || h6 == ks[1] || h6 == ks[2] || h6 == ks[3] || h6 == ks[4]);
+                if (!kspecial) {
+                    uint32_t kny = 0, kybase = 0, knx = 0, kxtop = 0;
+                    if (p >= lx) {
+                        const uint64_t e = kinv2y[p - lx];
+                        kny = (uint32_t)(e >> 32); kybase = (uint32_t)e - 1u;
+                        if (pair && p - lx <= DFL_MAX_DIST) { knx = kbsx[h6 + 1u] - kbsx[h6]; kxtop = kbsx[h6 + 1u] - 1u; }
+                    } else {
+                        const uint64_t e = kinv2x[p];
+                        knx = (uint32_t)(e >> 32); kxtop = (uint32_t)e - 1u;
+                    }
+                    const uint32_t ktotal = kny + knx;
+                    const bool p_in_y = p >= lx;
+                    for (uint32_t j0 = 0; j0 < ktotal; j0 += 64u) {
+                        const uint32_t j = j0 + lane;
+                        const bool in = j < ktotal;
+                        const bool fromy = j < kny;
+                        uint32_t v = 0, r3 = 0;
+                        uint64_t d8 = 0;
+                        if (in) {
+                            const uint32_t idx = fromy ? kybase - j : kxtop - (j - kny);
+                            v = (fromy ? koccy : koccx)[idx];
+                            d8 = (fromy ? kocc8y : kocc8x)[idx];
+                            r3 = (fromy ? kr3y : kr3x)[idx];
+                        }
+                        const uint32_t q = fromy ? lx + v : v;
+                        // position of q in the 3-byte chain of p (0 = its head)
+                        uint32_t j3;
+                        if (p_in_y) j3 = fromy ? ny - 1u - r3 : ny + nsp + (nx - 1u - r3);
+                        else j3 = nx - 1u - r3;
+                        const uint32_t h3 = ((((uint32_t)d8 & 0xffu) << 10) ^ ((((uint32_t)d8 >> 8) & 0xffu) << 5) ^
+                                             (((uint32_t)d8 >> 16) & 0xffu)) & 0x7fffu;
+                        const bool near = in && p - q <= (j3 == 0u ? DFL_MAX_DIST : DFL_MAX_DIST - 1u);
+                        const bool ok = near && q != 0u && h3 == h && j3 < chain;
+                        const bool whole = v + 8u <= (fromy ? S.ly : lx);
+                        uint64_t x8 = d8 ^ s0;
+                        if (ok && !whole) x8 = dfl_load8(S, q) ^ s0;
+                        const uint32_t len8 = (ok ? (x8 ? (uint32_t)__builtin_ctzll(x8) >> 3 : 8u) : 0u);
+                        uint64_t after = ~0ull;
+                        for (;;) {
+                            const uint32_t floor8 = best_len < 7u ? best_len : 7u;
+                            const uint64_t cand = __builtin_amdgcn_ballot_w64(len8 > floor8) & after;
+                            if (!cand) break;
+                            const uint32_t i = (uint32_t)__builtin_ctzll(cand);
+                            after = i < 63u ? ~((2ull << i) - 1ull) : 0ull;
+                            uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)len8, (int)i);
+                            const uint32_t qi = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)i);
+                            if (len == 8u) {
+                                while (len < DFL_MAX_MATCH) {
+                                    const uint64_t y8 = dfl_load8(S, p + len) ^ dfl_load8(S, qi + len);
+                                    if (y8) { len += (uint32_t)__builtin_ctzll(y8) >> 3; break; }
+                                    len += 8u;
+                                }
+                                if (len > DFL_MAX_MATCH) len = DFL_MAX_MATCH;
+                            }
+                            if (len > best_len) {
+                                best_len = len;
+                                match_start = qi;
+                                if (len >= nice) { done = true; break; }
+                            }
+                        }
+                        // the lists are in falling position order: behind the first member that is too far
+                        // (or the last of the bucket) nothing can follow
+                        if (done || __builtin_amdgcn_ballot_w64(in && !near) != 0ull) break;
+                    }
+                    if (best_len >= 6u && best_len > prev_length) {
+                        kdone = true; searched = true;
+                    } else if (prev_length >= 5u) {
+                        // nothing can beat prev_length without >= 6 matching bytes: zlib emits the previous
+                        // match whatever this search returns
+                        kdone = true;
+                    }
+                    if (!kdone) { best_len = prev_length; done = false; match_start = match_start_in; }
+                }
+            }
+
+            if (!kdone && total != 0u) {
                 const uint32_t lim = total < chain ? total : chain;
-                uint32_t best_len = prev_length;
-                bool searched = false, done = false;
                 // 256 candidates per step, four per lane, their loads in flight together.  Every lane
                 // gets the byte-exact common length within the first 8 bytes; the groups of 64 are then
                 // walked in chain order by "first lane that beats the best so far" (one ballot per round,
@@ -642,10 +781,10 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
                         if (nvalid < 64u) done = true;
                     }
                 }
-                if (searched) {
-                    match_length = best_len <= la ? best_len : la;
-                    if (match_length == 3u && p - match_start > DFL_TOO_FAR) match_length = 2u;
-                }
+            }
+            if (searched) {
+                match_length = best_len <= la ? best_len : la;
+                if (match_length == 3u && p - match_start > DFL_TOO_FAR) match_length = 2u;
             }
         }
         DFL_T(tb); acc_search += tb - ta;
@@ -829,11 +968,13 @@ struct DflState {
     int device = 0;
     int n = 0;
     int level = 0;                       // level the symbol streams were built for (0 = none)
-    bool indexed = false;
+    bool indexed = false, kindexed = false;
     std::vector<DflSeq> seq;
     DflSeq *d_seq = nullptr;
     uint32_t *d_occ = nullptr, *d_bstart = nullptr;
     uint64_t *d_occ8 = nullptr, *d_inv2 = nullptr;
+    uint32_t *d_kocc = nullptr, *d_kr3 = nullptr, *d_kbstart = nullptr;
+    uint64_t *d_kocc8 = nullptr, *d_kinv2 = nullptr;
     uint32_t *d_sym = nullptr, *d_pos = nullptr, *d_rhist = nullptr, *d_status = nullptr;
     uint64_t *d_cumbits = nullptr;
     DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
@@ -852,7 +993,8 @@ void dfl_destroy(void *v)
     DflState *s = (DflState *)v;
     if (!s) return;
     (void)hipSetDevice(s->device);
-    dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart); dfree(s->d_sym); dfree(s->d_pos);
+    dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart);
+    dfree(s->d_kocc); dfree(s->d_kr3); dfree(s->d_kbstart); dfree(s->d_kocc8); dfree(s->d_kinv2); dfree(s->d_sym); dfree(s->d_pos);
     dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
     dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -883,6 +1025,8 @@ DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
     T.bytes = v.d_bytes; T.seq = s->d_seq; T.occ = s->d_occ; T.occ8 = s->d_occ8; T.inv2 = s->d_inv2; T.bstart = s->d_bstart;
     T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
     T.seg_sym = s->d_seg_sym; T.seg_pos = s->d_seg_pos; T.seg_cnt = s->d_seg_cnt;
+    T.k_occ = s->d_kocc; T.k_r3 = s->d_kr3; T.k_bstart = s->d_kbstart; T.k_occ8 = s->d_kocc8; T.k_inv2 = s->d_kinv2;
+    T.use_k = (v.dfl_kmer && level == 9 && s->kindexed) ? 1u : 0u;   // pays off only for the 4096-member budget
     level_config(level, T);
     return T;
 }
@@ -929,8 +1073,12 @@ int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const st
     const uint32_t nj = (uint32_t)jobs.size();
     if (!s->ev0) { DCHK(c, hipEventCreate(&s->ev0)); DCHK(c, hipEventCreate(&s->ev1)); }
     DCHK(c, hipEventRecord(s->ev0, v.stream));
-    hipLaunchKernelGGL(dfl_parse_kernel, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
-                       v.stream, T, s->d_jobs, nj, s->d_out);
+    if (T.use_k)
+        hipLaunchKernelGGL(dfl_parse_kernel<true>, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
+                           v.stream, T, s->d_jobs, nj, s->d_out);
+    else
+        hipLaunchKernelGGL(dfl_parse_kernel<false>, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
+                           v.stream, T, s->d_jobs, nj, s->d_out);
     DCHK(c, hipGetLastError());
     DCHK(c, hipEventRecord(s->ev1, v.stream));
     if (host_out) {
@@ -975,7 +1123,7 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
     DCHK(c, hipMalloc((void **)&d_skey, cap * 2));
     DCHK(c, hipMalloc((void **)&d_val, cap * 4));
     {
-        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_skey, d_val, s->d_occ, (int)cap, 0, 15, v.stream);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_skey, d_val, s->d_occ, (int)cap, 0, 16, v.stream);
         if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort sizing failed");
     }
     DCHK(c, hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
@@ -1004,6 +1152,54 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
     return SNK_OK;
 }
 
+// The six-byte index (level 9 only; built on first use).
+int dfl_build_kindex(snk_ctx *c, DflState *s, const SnkSeqView &v)
+{
+    const size_t n = (size_t)v.n;
+    uint64_t itot = 0;
+    uint32_t maxlen = 0;
+    for (const DflSeq &q : s->seq) { itot += (uint64_t)q.len + 1u; maxlen = std::max(maxlen, q.len); }
+    DCHK(c, hipMalloc((void **)&s->d_kocc, itot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_kr3, itot * 4));
+    DCHK(c, hipMalloc((void **)&s->d_kocc8, itot * 8));
+    DCHK(c, hipMalloc((void **)&s->d_kinv2, itot * 8));
+    DCHK(c, hipMalloc((void **)&s->d_kbstart, n * 65537u * 4));
+    uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    const size_t cap = (size_t)maxlen + 1u;
+    DCHK(c, hipMalloc((void **)&d_key, cap * 2));
+    DCHK(c, hipMalloc((void **)&d_skey, cap * 2));
+    DCHK(c, hipMalloc((void **)&d_val, cap * 4));
+    {
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_skey, d_val, s->d_kocc, (int)cap, 0, 16, v.stream);
+        if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort sizing failed");
+    }
+    DCHK(c, hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    for (size_t g = 0; g < n; ++g) {
+        const DflSeq &q = s->seq[g];
+        // the six-byte index (positions <= len - 6), same construction
+        const uint32_t m6 = q.len >= 6u ? q.len - 5u : 0u;
+        uint32_t *kbst = s->d_kbstart + g * 65537u;
+        if (m6) {
+            const uint32_t grid = std::min<uint32_t>((m6 + 255u) / 256u, 4096u);
+            hipLaunchKernelGGL(dfl_khash_kernel, dim3(grid), dim3(256), 0, v.stream, v.d_bytes + q.boff, m6, d_key, d_val);
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_skey, d_val, s->d_kocc + q.ioff, (int)m6, 0, 16, v.stream);
+            if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort failed");
+        }
+        hipLaunchKernelGGL(dfl_kbstart_kernel, dim3((65537u + 255u) / 256u), dim3(256), 0, v.stream, d_skey, m6, kbst);
+        if (m6) {
+            const uint32_t grid = std::min<uint32_t>((m6 + 255u) / 256u, 4096u);
+            hipLaunchKernelGGL(dfl_kinv_kernel, dim3(grid), dim3(256), 0, v.stream, s->d_kocc + q.ioff, d_skey, kbst,
+                               v.d_bytes + q.boff, s->d_inv2 + q.ioff, m6, s->d_kinv2 + q.ioff, s->d_kocc8 + q.ioff, s->d_kr3 + q.ioff);
+        }
+    }
+    DCHK(c, hipGetLastError());
+    DCHK(c, hipStreamSynchronize(v.stream));
+    dfree(d_key); dfree(d_skey); dfree(d_val);
+    if (d_tmp) (void)hipFree(d_tmp);
+    s->kindexed = true;
+    return SNK_OK;
+}
+
 int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
 {
     DflTables cfg{};
@@ -1012,6 +1208,7 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     if (rc != SNK_OK) return rc;
     DCHK(c, hipSetDevice(v.device));
     if (!s->indexed) { rc = dfl_build_index(c, s, v); if (rc != SNK_OK) return rc; }
+    if (level == 9 && v.dfl_kmer && !s->kindexed) { rc = dfl_build_kindex(c, s, v); if (rc != SNK_OK) return rc; }
     if (s->level == level) return SNK_OK;
     // stand-alone stream of every sequence at this level
     for (auto &q : s->seq) { q.nsym = 0; q.unsafe = 0; q.total_bits = 0; q.rk = q.rpos = q.rkb = q.rbpos = 0; }

@@ -14,6 +14,7 @@ struct SnkSeqView {
     const uint32_t *len;      // host: length of each
     const uint32_t *boff;     // host: byte offset of each in d_bytes (zero padded behind)
     const uint8_t *d_bytes;   // device: the ASCII arena
+    int dfl_kmer;             // option "deflate_kmer" (default 1): use the six-byte index in the match search
     int dfl_serial;           // option "deflate_serial": per-sequence pass by one wave per sequence (testing)
 };
 

@@ -102,6 +102,29 @@ def test_segmented_and_serial_sequence_passes_agree(hip, oracle_mod):
                 assert int(pa[i, j]) == len(fn(raw[i] + raw[j])), (alg, i, j)
 
 
+def test_six_byte_index_on_and_off_agree(hip, oracle_mod):
+    """gzip's match search first tries the chain members that share six bytes with the probe (second index);
+    `deflate_kmer=0` walks every chain in full.  Same sizes -- on genomes, relatives, low-complexity and
+    protein-like data, and across the seam (pairs)."""
+    rng = np.random.default_rng(31)
+    x = oracle_mod.lcg_genome(80, 180000)
+    y = x.copy()
+    hit = rng.random(len(y)) < 0.01
+    y[hit] = rng.choice(ACGT, int(hit.sum()))
+    seqs = [x, y[3000:], oracle_mod.lcg_genome(81, 90000), rng.choice(np.frombuffer(b"AC", dtype=np.uint8), 60000),
+            rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8), 70000),
+            np.repeat(rng.choice(ACGT, 4000), 30)[:100000].copy(), x[:70], x[:6], x[:5]]
+    with hip.HipContext(0) as a, hip.HipContext(0, deflate_kmer=0) as b:
+        a.upload(seqs)
+        b.upload(seqs)
+        assert np.array_equal(a.deflate_singles("gzip"), b.deflate_singles("gzip"))
+        pa, pb = a.deflate_pairs("gzip"), b.deflate_pairs("gzip")
+        assert np.array_equal(pa, pb)
+    raw = [_b(s) for s in seqs]
+    for i, j in ((0, 1), (1, 0), (2, 3), (5, 0), (6, 7), (8, 6), (0, 8)):
+        assert int(pa[i, j]) == len(gzip.compress(raw[i] + raw[j])), (i, j)
+
+
 def test_pair_lists_tiles_and_single_items(hip, oracle_mod):
     seqs = [oracle_mod.lcg_genome(60 + i, 66000 + 7777 * i) for i in range(7)]
     with hip.HipContext(0) as ctx:
