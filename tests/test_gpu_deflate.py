@@ -138,6 +138,20 @@ def test_pair_lists_tiles_and_single_items(hip, oracle_mod):
             assert np.array_equal(ctx.deflate_pairs_list(alg, [(i, -1) for i in range(7)]), ctx.deflate_singles(alg))
 
 
+def test_second_upload_replaces_indexes_and_streams(hip, oracle_mod):
+    a = [oracle_mod.lcg_genome(90 + i, 70000 + 900 * i) for i in range(4)]
+    b = [oracle_mod.lcg_genome(95 + i, 40000 + 30000 * i) for i in range(3)]
+    with hip.HipContext(0) as ctx:
+        for seqs in (a, b, a[:2]):
+            ctx.upload(seqs)
+            raw = [_b(s) for s in seqs]
+            for alg, fn in CODEC.items():
+                assert [int(v) for v in ctx.deflate_singles(alg)] == [len(fn(r)) for r in raw]
+                p = ctx.deflate_pairs(alg)
+                assert int(p[1, 0]) == len(fn(raw[1] + raw[0])) and int(p[0, len(seqs) - 1]) == len(fn(raw[0] + raw[-1]))
+            assert ctx.singles().shape == (len(seqs),)        # the lz4 side of the same context still works
+
+
 def test_1mbp_pairs_sample_against_the_oracle(hip, oracle_mod):
     """BASELINE's 1 Mbp size: the full 12 x 12 matrices on the GPU, a sample of pairs against the CPU
     oracle (about 2 s per gzip pair there), plus properties that need no oracle."""
