@@ -573,43 +573,26 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     uint32_t match_length = 2u, match_start = 0u;
     bool match_available = false;
 
-    // The probe of p needs three uniform reads before anything else: the 8 bytes at p and p's entries in the
-    // two indexes.  Most probes are followed by the one at p + 1, so those reads are issued one probe ahead.
-    uint32_t pf_p = 0xFFFFFFFFu;
-    uint64_t pf_s0 = 0, pf_e3 = 0, pf_e6 = 0;
     while (p < n) {
         const uint32_t la = n - p;
         const uint32_t prev_length = match_length, prev_match = match_start;
-        uint64_t cur_s0, cur_e3, cur_e6;
-        if (p == pf_p) { cur_s0 = pf_s0; cur_e3 = pf_e3; cur_e6 = pf_e6; }
-        else {
-            cur_s0 = dfl_load8(S, p);
-            cur_e3 = p >= lx ? inv2y[p - lx] : inv2x[p];
-            cur_e6 = USE_K ? (p >= lx ? kinv2y[p - lx] : kinv2x[p]) : 0ull;
-        }
-        if (p + 1u < n) {
-            pf_p = p + 1u;
-            pf_s0 = dfl_load8(S, pf_p);
-            pf_e3 = pf_p >= lx ? inv2y[pf_p - lx] : inv2x[pf_p];
-            pf_e6 = USE_K ? (pf_p >= lx ? kinv2y[pf_p - lx] : kinv2x[pf_p]) : 0ull;
-        }
         match_length = 2u;
         DFL_T(ta); iters++;
         if (la >= 3u && prev_length < T.lazy) {
             // ---- the chain of p: earlier positions with the same hash, most recent first ----
-            const uint64_t s0 = cur_s0;                          // la >= 3: its first three bytes are input
+            const uint64_t s0 = dfl_load8(S, p);                 // la >= 3: its first three bytes are input
             const uint32_t h = ((((uint32_t)s0 & 0xffu) << 10) ^ ((((uint32_t)s0 >> 8) & 0xffu) << 5) ^
                                 (((uint32_t)s0 >> 16) & 0xffu)) & 0x7fffu;
             uint32_t ny = 0, ybase = 0, nsp = 0, sp0 = 0, sp1 = 0, nx = 0, xtop = 0;
             if (p >= lx) {
-                const uint64_t e = cur_e3;
+                const uint64_t e = inv2y[p - lx];
                 ny = (uint32_t)(e >> 32); ybase = (uint32_t)e - 1u;
                 if (hs1 == h) { sp0 = lx - 1u; nsp = 1u; }
                 if (hs2 == h) { if (nsp) sp1 = lx - 2u; else sp0 = lx - 2u; nsp++; }
                 // x's bucket is needed only while the chain can still reach the seam
                 if (pair && p - lx <= DFL_MAX_DIST) { nx = bsx[h + 1u] - bsx[h]; xtop = bsx[h + 1u] - 1u; }
             } else if (p + 3u <= lx) {
-                const uint64_t e = cur_e3;
+                const uint64_t e = inv2x[p];
                 nx = (uint32_t)(e >> 32); xtop = (uint32_t)e - 1u;
             } else {
                 if (p == lx - 1u && hs2 == h) { sp0 = lx - 2u; nsp = 1u; }
@@ -635,11 +618,11 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
                 if (!kspecial) {
                     uint32_t kny = 0, kybase = 0, knx = 0, kxtop = 0;
                     if (p >= lx) {
-                        const uint64_t e = cur_e6;
+                        const uint64_t e = kinv2y[p - lx];
                         kny = (uint32_t)(e >> 32); kybase = (uint32_t)e - 1u;
                         if (pair && p - lx <= DFL_MAX_DIST) { knx = kbsx[h6 + 1u] - kbsx[h6]; kxtop = kbsx[h6 + 1u] - 1u; }
                     } else {
-                        const uint64_t e = cur_e6;
+                        const uint64_t e = kinv2x[p];
                         knx = (uint32_t)(e >> 32); kxtop = (uint32_t)e - 1u;
                     }
                     const uint32_t ktotal = kny + knx;
