@@ -263,6 +263,26 @@ def main():
                             "log_fixed_lines": [ln.replace(str(d) + "/", "{DIR}/") for ln in log_lines
                                                 if not ln.startswith(("* Analysis", "* Output", "* Python", "* snacc", "* py-lz4framed"))]}
 
+    # ---- 3. gzip / zlib sizes from the codec the reference calls (ref:snacc/pairwise_ncd.py:73-78) -------
+    import gzip
+    import zlib
+    dfl = {"zlib_version": zlib.ZLIB_RUNTIME_VERSION, "python": sys.version.split()[0], "cases": []}
+    for n in (1000, 100000, 1000000):
+        x, y = lcg_genome(1, n), lcg_genome(2, n)
+        z = lcg_mutant(x, 3)
+        row = {"n": n}
+        for name, data in (("x", x), ("y", y), ("z", z), ("xy", x + y), ("yx", y + x), ("xx", x + x), ("xz", x + z)):
+            row[name] = {"gzip": len(gzip.compress(data)), "zlib": len(zlib.compress(data))}
+        dfl["cases"].append(row)
+    dfl["ragged"] = [{"n": n, "seed": 21, "gzip": len(gzip.compress(lcg_genome(21, n))), "zlib": len(zlib.compress(lcg_genome(21, n)))}
+                     for n in (0, 1, 2, 3, 4, 100, 32768, 65274, 65275, 65536, 65537, 65798, 98304, 131073, 200001)]
+    dfl["other_alphabets"] = [{"name": name, "alphabet_hex": alpha.hex(), "seed": seed, "n": n,
+                               "gzip": len(gzip.compress(lcg_bytes(seed, n, alpha))), "zlib": len(zlib.compress(lcg_bytes(seed, n, alpha)))}
+                              for name, alpha, seed, n in (("aa20", b"ACDEFGHIKLMNPQRSTVWY", 31, 150000),
+                                                          ("bytes256", bytes(range(256)), 32, 150000),
+                                                          ("acgtn", b"ACGTN", 33, 150000), ("two", b"AC", 34, 150000))]
+    gold["deflate_sizes"] = dfl
+
     out_path = Path(__file__).with_name("golden.json")
     out_path.write_text(json.dumps(gold, indent=1, sort_keys=True) + "\n")
     print("wrote", out_path, out_path.stat().st_size, "bytes")

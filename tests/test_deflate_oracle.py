@@ -92,3 +92,27 @@ def test_block_cost_function_matches_stream(D, oracle_mod):
             lf[s] += 1
     assert D.block_bits(lf, df) == int(blk[0])
     assert (int(blk.sum()) + 7) // 8 == raw
+
+
+def test_golden_deflate_sizes(D, golden, oracle_mod):
+    """Committed sizes produced by zlib 1.2.11 (tests/golden/make_golden.py): pins the oracle to that version
+    even where the interpreter running the tests links another zlib."""
+    g = golden["deflate_sizes"]
+    assert g["zlib_version"] == "1.2.11"
+    from conftest import lcg_bytes
+    for row in g["cases"]:
+        n = row["n"]
+        x, y = oracle_mod.lcg_genome(1, n), oracle_mod.lcg_genome(2, n)
+        z = oracle_mod.lcg_mutant(x, 3)
+        parts = {"x": (x, None), "y": (y, None), "z": (z, None), "xy": (x, y), "yx": (y, x), "xx": (x, x), "xz": (x, z)}
+        for name, (a, b) in parts.items():
+            if n == 1000000 and name not in ("x", "xy", "xz"):
+                continue                                   # keep the CPU suite short
+            assert D.gzip_size(a, b) == row[name]["gzip"], (n, name)
+            assert D.zlib_size(a, b) == row[name]["zlib"], (n, name)
+    for r in g["ragged"]:
+        a = oracle_mod.lcg_genome(r["seed"], r["n"])
+        assert (D.gzip_size(a), D.zlib_size(a)) == (r["gzip"], r["zlib"]), r["n"]
+    for r in g["other_alphabets"]:
+        a = lcg_bytes(r["seed"], r["n"], bytes.fromhex(r["alphabet_hex"]))
+        assert (D.gzip_size(a), D.zlib_size(a)) == (r["gzip"], r["zlib"]), r["name"]

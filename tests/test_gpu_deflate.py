@@ -168,6 +168,30 @@ def test_1mbp_pairs_sample_against_the_oracle(hip, oracle_mod):
             assert int(s[4]) == fn(seqs[4])
 
 
+def test_golden_deflate_sizes_through_cabi(hip, golden, oracle_mod):
+    """The committed zlib-1.2.11 sizes (tests/golden/golden.json), singles and pairs up to 1 Mbp, through the C-ABI."""
+    from conftest import lcg_bytes
+    g = golden["deflate_sizes"]
+    for row in g["cases"]:
+        n = row["n"]
+        x, y = oracle_mod.lcg_genome(1, n), oracle_mod.lcg_genome(2, n)
+        z = oracle_mod.lcg_mutant(x, 3)
+        with hip.HipContext(0) as ctx:
+            ctx.upload([x, y, z])
+            for alg in ("gzip", "zlib"):
+                s = ctx.deflate_singles(alg)
+                assert [int(v) for v in s] == [row[k][alg] for k in ("x", "y", "z")], (n, alg)
+                p = ctx.deflate_pairs_list(alg, [(0, 1), (1, 0), (0, 0), (0, 2)])
+                assert [int(v) for v in p] == [row[k][alg] for k in ("xy", "yx", "xx", "xz")], (n, alg)
+    seqs = [oracle_mod.lcg_genome(r["seed"], r["n"]) for r in g["ragged"]]
+    seqs += [lcg_bytes(r["seed"], r["n"], bytes.fromhex(r["alphabet_hex"])) for r in g["other_alphabets"]]
+    exp = g["ragged"] + g["other_alphabets"]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        for alg in ("gzip", "zlib"):
+            assert [int(v) for v in ctx.deflate_singles(alg)] == [r[alg] for r in exp], alg
+
+
 def test_python_batched_api_and_ncd(hip, oracle_mod):
     from snacc_amd.pairwise_ncd import all_pairs, ncd_matrix_gpu, compute_distance
     seqs = [bytes(oracle_mod.lcg_genome(30 + i, 40000 + 5000 * i)) for i in range(5)]
