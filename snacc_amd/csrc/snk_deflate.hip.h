@@ -26,10 +26,12 @@ constexpr uint32_t L_FREQ = L_HEAP + 2 * 576;          // u16[576]
 constexpr uint32_t L_DAD = L_FREQ + 2 * 576;           // u16[576]
 constexpr uint32_t L_LEN = L_DAD + 2 * 576;            // u16[576]
 constexpr uint32_t L_DEPTH = L_LEN + 2 * 576;          // u8[576]
-constexpr uint32_t L_LLEN = L_DEPTH + 576;             // u8[288]  code lengths of the literal/length tree
-constexpr uint32_t L_DLEN = L_LLEN + 288;              // u8[32]   code lengths of the distance tree
-constexpr uint32_t L_MISC = L_DLEN + 32;               // u32[8]   results of lane 0
-constexpr uint32_t L_WAVE = L_MISC + 32;               // 6848
+// the saved code lengths live in the histogram's memory: by the time they are written the counts they
+// overwrite (literal codes 0..79) have been copied into the tree arrays, and the histogram is rebuilt afterwards
+constexpr uint32_t L_LLEN = L_HIST;                    // u8[288]  code lengths of the literal/length tree
+constexpr uint32_t L_DLEN = L_HIST + 288;              // u8[32]   code lengths of the distance tree
+constexpr uint32_t L_MISC = L_DEPTH + 576;             // u32[8]   results of lane 0
+constexpr uint32_t L_WAVE = L_MISC + 32;               // 6496: 4 waves = 25 984 B per workgroup, 6 workgroups per CU
 
 struct DflSeq {              // one per resident sequence (device + host mirror)
     uint32_t boff, len;
@@ -485,7 +487,7 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
 
 // USE_K: with the six-byte index in the match search (level 9)
 template <bool USE_K>
-__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(5)))
+__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(6)))
 dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
     extern __shared__ __align__(16) uint8_t dfl_lds[];
