@@ -287,7 +287,10 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     if (s->level == level) return SNK_OK;
     // stand-alone stream of every sequence at this level
     for (auto &q : s->seq) { q.nsym = 0; q.unsafe = 0; q.total_bits = 0; q.rk = q.rpos = q.rkb = q.rbpos = 0; }
-    DCHK(c, hipMemcpy(s->d_seq, s->seq.data(), s->seq.size() * sizeof(DflSeq), hipMemcpyHostToDevice));
+    // (every copy and memset below is ordered on v.stream: the kernels run there, and it does not synchronise
+    // with the null stream)
+    DCHK(c, hipMemcpyAsync(s->d_seq, s->seq.data(), s->seq.size() * sizeof(DflSeq), hipMemcpyHostToDevice, v.stream));
+    DCHK(c, hipStreamSynchronize(v.stream));
     s->single.assign((size_t)v.n, 0u);
     std::vector<int> serial;                 // sequences parsed by one wave from start to end
     if (v.dfl_serial) {
@@ -304,7 +307,7 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
                 DflSeg sg{};
                 sg.p0 = i * DFL_SEG; sg.p1 = std::min<uint64_t>((uint64_t)(i + 1u) * DFL_SEG, len);
                 sg.first = i == 0u; sg.aux = aux; sg.cnt = 0;
-                aux += (uint64_t)(sg.p1 - sg.p0) + DFL_SEG_SLACK + 300u;
+                aux += (uint64_t)(sg.p1 - sg.p0) + DFL_SEG_SLACK + DFL_SEG_ROOM;
                 segs.push_back(sg); seg_seq.push_back(g);
             }
         }
@@ -318,8 +321,9 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
         DCHK(c, hipMalloc((void **)&d_from, ns * 4)); DCHK(c, hipMalloc((void **)&d_ends, ns * 4));
         DCHK(c, hipMalloc((void **)&d_fail, ns * 4)); DCHK(c, hipMalloc((void **)&d_num, ns * 4));
         DCHK(c, hipMalloc((void **)&d_dst, ns * 8));
-        DCHK(c, hipMemcpy(d_segs, segs.data(), ns * sizeof(DflSeg), hipMemcpyHostToDevice));
-        DCHK(c, hipMemset(d_fail, 0, ns * 4));
+        DCHK(c, hipMemcpyAsync(d_segs, segs.data(), ns * sizeof(DflSeg), hipMemcpyHostToDevice, v.stream));
+        DCHK(c, hipMemsetAsync(d_fail, 0, ns * 4, v.stream));
+        DCHK(c, hipStreamSynchronize(v.stream));
         std::vector<DflJob> jobs(ns);
         for (size_t t = 0; t < ns; ++t) jobs[t] = DflJob{seg_seq[t], -1, 2u, (uint32_t)t, segs[t].p0, segs[t].p1, segs[t].aux};
         rc = dfl_launch(c, s, v, level, jobs, nullptr);
@@ -355,8 +359,8 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
             }
             t = e;
         }
-        DCHK(c, hipMemcpy(d_num, num.data(), ns * 4, hipMemcpyHostToDevice));
-        DCHK(c, hipMemcpy(d_dst, dst.data(), ns * 8, hipMemcpyHostToDevice));
+        DCHK(c, hipMemcpyAsync(d_num, num.data(), ns * 4, hipMemcpyHostToDevice, v.stream));
+        DCHK(c, hipMemcpyAsync(d_dst, dst.data(), ns * 8, hipMemcpyHostToDevice, v.stream));
         hipLaunchKernelGGL(dfl_compact_kernel, dim3((uint32_t)ns), dim3(256), 0, v.stream, d_segs, d_from, d_num, d_dst,
                            s->d_seg_sym, s->d_seg_pos, s->d_sym, s->d_pos);
         DCHK(c, hipGetLastError());
@@ -379,7 +383,8 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     hipLaunchKernelGGL(dfl_restart_kernel, dim3((uint32_t)v.n), dim3(64), 0, v.stream, T, (uint32_t)v.n);
     DCHK(c, hipGetLastError());
     DCHK(c, hipStreamSynchronize(v.stream));
-    DCHK(c, hipMemcpy(s->seq.data(), s->d_seq, s->seq.size() * sizeof(DflSeq), hipMemcpyDeviceToHost));
+    DCHK(c, hipMemcpyAsync(s->seq.data(), s->d_seq, s->seq.size() * sizeof(DflSeq), hipMemcpyDeviceToHost, v.stream));
+    DCHK(c, hipStreamSynchronize(v.stream));
     for (int g = 0; g < v.n; ++g) s->single[(size_t)g] = (uint32_t)(s->seq[(size_t)g].total_bits >> 3);
     s->level = level;
     return SNK_OK;
@@ -390,6 +395,21 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
 extern "C" {
 
 #ifdef DFL_STAMP
+/* diagnostic build only: the stored symbol stream of sequence g (cap entries) and its restart record */
+int snk_debug_dfl_stream(snk_ctx *c, int g, uint32_t *sym, uint32_t *pos, uint32_t cap, uint32_t *info /* [8] */)
+{
+    void **slot = snk_internal_dfl_slot(c, nullptr);
+    DflState *s = (DflState *)*slot;
+    if (!s || g < 0 || g >= s->n) return -1;
+    DflSeq q;
+    if (hipMemcpy(&q, s->d_seq + g, sizeof q, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const uint32_t k = q.nsym < cap ? q.nsym : cap;
+    if (hipMemcpy(sym, s->d_sym + q.soff, (size_t)k * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(pos, s->d_pos + q.soff, (size_t)k * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    info[0] = q.nsym; info[1] = q.unsafe; info[2] = q.rk; info[3] = q.rpos; info[4] = q.rkb; info[5] = q.rbpos;
+    info[6] = (uint32_t)(q.total_bits >> 3); info[7] = (uint32_t)s->n_serial;
+    return 0;
+}
 int snk_debug_dfl_stamps(unsigned long long *out /* [64*8] */)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(dfl_stamp_buf), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;

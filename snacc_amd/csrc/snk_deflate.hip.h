@@ -51,6 +51,7 @@ struct DflSeq {              // one per resident sequence (device + host mirror)
 struct DflJob { int32_t xi, yi; uint32_t mode, out_idx; uint32_t p0, p1; uint64_t aux; };
 constexpr uint32_t DFL_SEG = 32768u;           // segment length of the parallel per-sequence pass
 constexpr uint32_t DFL_SEG_SLACK = 2048u;      // a segment runs this far into the next one, for the stitch
+constexpr uint32_t DFL_SEG_ROOM = 300u;        // scratch entries beyond that (one match can carry the parser 258 further)
 
 struct DflTables {
     const uint8_t *bytes;
@@ -569,6 +570,9 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     const uint32_t *symy = T.sym + sy.soff, *posy = T.pos + sy.soff;
     uint32_t sync_k = mode == 3u ? 0u : 0xFFFFFFFFu;              // pricing = "synchronised" with the own stream at symbol 0
     const uint32_t seg_stop = (mode == 2u && job.p1 < n) ? job.p1 + DFL_SEG_SLACK : 0xFFFFFFFFu;
+    // a segment stops behind the first match past seg_stop -- or, on data with hardly any match, when its
+    // scratch stream is full (the stitch then finds no common point and the sequence is parsed serially)
+    const uint32_t seg_cap = mode == 2u ? (job.p1 - job.p0) + DFL_SEG_SLACK + DFL_SEG_ROOM - 2u : 0xFFFFFFFFu;
     const uint32_t yoff = mode == 3u ? 0u : lx;                  // stream position of the streamed symbols' base
     const uint32_t ynsym = sy.nsym;
 
@@ -576,6 +580,7 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     bool match_available = false;
 
     while (p < n) {
+        if (w.nsym >= seg_cap) break;
         const uint32_t la = n - p;
         const uint32_t prev_length = match_length, prev_match = match_start;
         match_length = 2u;
@@ -629,9 +634,12 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
                     }
                     const uint32_t ktotal = kny + knx;
                     const bool p_in_y = p >= lx;
-                    for (uint32_t j0 = 0; j0 < ktotal; j0 += 64u) {
+                    // the bucket holds every earlier position of the sequence with this hash, the window only the
+                    // most recent few (about 8 on DNA): look at 16 first, then 64 at a time
+                    uint32_t width = 16u;
+                    for (uint32_t j0 = 0; j0 < ktotal; j0 += width, width = 64u) {
                         const uint32_t j = j0 + lane;
-                        const bool in = j < ktotal;
+                        const bool in = j < ktotal && lane < width;
                         const bool fromy = j < kny;
                         uint32_t v = 0, r3 = 0;
                         uint64_t d8 = 0;
@@ -797,21 +805,31 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
         __builtin_amdgcn_wave_barrier();
         while (k < ynsym) {
             uint32_t m = ynsym - k;
-            if (m > 64u) m = 64u;
+            if (m > 256u) m = 256u;                               // four symbols per lane, their loads in flight together
             if (m > DFL_BLOCK_SYMS - w.bcount) m = DFL_BLOCK_SYMS - w.bcount;
-            uint32_t s = 0;
-            if (lane < m) {
-                s = symy[k + lane];
-                if (s >> 31) {
-                    atomicAdd(&w.L.hist[257u + dfl_lcode((s >> 16) & 0x7fffu)], 1u);
-                    atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((s & 0xffffu) - 1u)], 1u);
-                } else {
-                    atomicAdd(&w.L.hist[s], 1u);
+            uint32_t sv[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t idx = lane + 64u * u;
+                sv[u] = idx < m ? symy[k + idx] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                if (lane + 64u * u < m) {
+                    const uint32_t sy1 = sv[u];
+                    if (sy1 >> 31) {
+                        atomicAdd(&w.L.hist[257u + dfl_lcode((sy1 >> 16) & 0x7fffu)], 1u);
+                        atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((sy1 & 0xffffu) - 1u)], 1u);
+                    } else {
+                        atomicAdd(&w.L.hist[sy1], 1u);
+                    }
                 }
             }
             k += m; w.bcount += m; w.nsym += m;
             if (w.bcount == DFL_BLOCK_SYMS) {
-                const uint32_t sl = (uint32_t)__shfl((int)s, (int)(m - 1u), 64);
+                const uint32_t last = m - 1u;
+                const uint32_t pick = (last >> 6) == 0u ? sv[0] : ((last >> 6) == 1u ? sv[1] : ((last >> 6) == 2u ? sv[2] : sv[3]));
+                const uint32_t sl = (uint32_t)__shfl((int)pick, (int)(last & 63u), 64);
                 const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();

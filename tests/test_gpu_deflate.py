@@ -102,6 +102,18 @@ def test_segmented_and_serial_sequence_passes_agree(hip, oracle_mod):
                 assert int(pa[i, j]) == len(fn(raw[i] + raw[j])), (alg, i, j)
 
 
+def test_segments_on_data_with_rare_matches(hip, oracle_mod):
+    """Regression (found by tools/gpu_deflate_fuzz.py, seeds 20016 and 20508): a segment job stops behind a match; on
+    data with hardly any match (stretches of random bytes) it ran on and overflowed its scratch stream into the
+    next segment's, and the block that is open at the restart point got wrong symbol counts.  The two sequence
+    sets of those seeds, singles and all pairs, against the codec."""
+    from fuzzgen import make_set
+    for seed, repeats in ((20016, 5), (20508, 2)):       # the overflow raced with the neighbour's own writes: repeat
+        seqs = make_set(seed)
+        for _ in range(repeats):
+            _check_all_vs_codec(hip, seqs)
+
+
 def test_six_byte_index_on_and_off_agree(hip, oracle_mod):
     """gzip's match search first tries the chain members that share six bytes with the probe (second index);
     `deflate_kmer=0` walks every chain in full.  Same sizes -- on genomes, relatives, low-complexity and
