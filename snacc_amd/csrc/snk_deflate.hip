@@ -148,12 +148,12 @@ int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const st
     const uint32_t nj = (uint32_t)jobs.size();
     if (!s->ev0) { DCHK(c, hipEventCreate(&s->ev0)); DCHK(c, hipEventCreate(&s->ev1)); }
     DCHK(c, hipEventRecord(s->ev0, v.stream));
-    if (T.use_k)
-        hipLaunchKernelGGL(dfl_parse_kernel<true>, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
-                           v.stream, T, s->d_jobs, nj, s->d_out);
-    else
-        hipLaunchKernelGGL(dfl_parse_kernel<false>, dim3((nj + DFL_WAVES - 1u) / DFL_WAVES), dim3(64 * DFL_WAVES), DFL_WAVES * L_WAVE,
-                           v.stream, T, s->d_jobs, nj, s->d_out);
+    const bool seg = jobs[0].mode == 2u;                     // a launch is all segment jobs or none
+    const dim3 grid((nj + DFL_WAVES - 1u) / DFL_WAVES), block(64 * DFL_WAVES);
+    if (T.use_k && seg)       hipLaunchKernelGGL((dfl_parse_kernel<true, true>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
+    else if (T.use_k)         hipLaunchKernelGGL((dfl_parse_kernel<true, false>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
+    else if (seg)             hipLaunchKernelGGL((dfl_parse_kernel<false, true>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
+    else                      hipLaunchKernelGGL((dfl_parse_kernel<false, false>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
     DCHK(c, hipGetLastError());
     DCHK(c, hipEventRecord(s->ev1, v.stream));
     if (host_out) {

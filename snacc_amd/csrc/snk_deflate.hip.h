@@ -486,8 +486,8 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
     }
 }
 
-// USE_K: with the six-byte index in the match search (level 9)
-template <bool USE_K>
+// USE_K: with the six-byte index in the match search (level 9);  SEG: the launch consists of segment jobs (mode 2)
+template <bool USE_K, bool SEG>
 __global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(6)))
 dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
@@ -580,7 +580,7 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     bool match_available = false;
 
     while (p < n) {
-        if (w.nsym >= seg_cap) break;
+        if (SEG && w.nsym >= seg_cap) break;
         const uint32_t la = n - p;
         const uint32_t prev_length = match_length, prev_match = match_start;
         match_length = 2u;
@@ -805,31 +805,30 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
         __builtin_amdgcn_wave_barrier();
         while (k < ynsym) {
             uint32_t m = ynsym - k;
-            if (m > 256u) m = 256u;                               // four symbols per lane, their loads in flight together
+            if (m > 128u) m = 128u;                               // two symbols per lane, their loads in flight together
             if (m > DFL_BLOCK_SYMS - w.bcount) m = DFL_BLOCK_SYMS - w.bcount;
-            uint32_t sv[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                const uint32_t idx = lane + 64u * u;
-                sv[u] = idx < m ? symy[k + idx] : 0u;
+            const uint32_t s0v = lane < m ? symy[k + lane] : 0u;
+            const uint32_t s1v = lane + 64u < m ? symy[k + lane + 64u] : 0u;
+            if (lane < m) {
+                if (s0v >> 31) {
+                    atomicAdd(&w.L.hist[257u + dfl_lcode((s0v >> 16) & 0x7fffu)], 1u);
+                    atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((s0v & 0xffffu) - 1u)], 1u);
+                } else {
+                    atomicAdd(&w.L.hist[s0v], 1u);
+                }
             }
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                if (lane + 64u * u < m) {
-                    const uint32_t sy1 = sv[u];
-                    if (sy1 >> 31) {
-                        atomicAdd(&w.L.hist[257u + dfl_lcode((sy1 >> 16) & 0x7fffu)], 1u);
-                        atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((sy1 & 0xffffu) - 1u)], 1u);
-                    } else {
-                        atomicAdd(&w.L.hist[sy1], 1u);
-                    }
+            if (lane + 64u < m) {
+                if (s1v >> 31) {
+                    atomicAdd(&w.L.hist[257u + dfl_lcode((s1v >> 16) & 0x7fffu)], 1u);
+                    atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((s1v & 0xffffu) - 1u)], 1u);
+                } else {
+                    atomicAdd(&w.L.hist[s1v], 1u);
                 }
             }
             k += m; w.bcount += m; w.nsym += m;
             if (w.bcount == DFL_BLOCK_SYMS) {
                 const uint32_t last = m - 1u;
-                const uint32_t pick = (last >> 6) == 0u ? sv[0] : ((last >> 6) == 1u ? sv[1] : ((last >> 6) == 2u ? sv[2] : sv[3]));
-                const uint32_t sl = (uint32_t)__shfl((int)pick, (int)(last & 63u), 64);
+                const uint32_t sl = (uint32_t)__shfl((int)(last >= 64u ? s1v : s0v), (int)(last & 63u), 64);
                 const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();
