@@ -73,6 +73,8 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   instead of in stitched parallel segments (testing; set before the first deflate call)
  *   "deflate_kmer"  0 = gzip / zlib: search every hash chain in full instead of first trying the members that
  *                   share six bytes with the probe (testing; same results)
+ *   "deflate_norestart" 1 = gzip / zlib: a pair job parses x from its first byte instead of restarting from x's
+ *                   stored stream shortly before the seam (testing; same results)
  *   "content_size"  1 = add the 8-byte content-size field to every frame
  *                   (py-lz4framed builds that set it)        */
 int snk_set_option(snk_ctx *ctx, const char *key, long value);

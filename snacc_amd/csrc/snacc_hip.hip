@@ -48,7 +48,7 @@ struct snk_ctx_impl {
     std::vector<uint8_t> is_packed;
     // deflate add-on (snk_deflate.hip): opaque state + its destructor
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
-    bool dfl_serial = false, dfl_kmer = true;
+    bool dfl_serial = false, dfl_kmer = true, dfl_norestart = false;
     uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_zero = nullptr;
     const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
@@ -320,6 +320,7 @@ int snk_internal_view(snk_ctx *c, SnkSeqView *v)
     v->len = c->len.data(); v->boff = c->boff.data(); v->d_bytes = c->d_bytes;
     v->dfl_serial = c->dfl_serial ? 1 : 0;
     v->dfl_kmer = c->dfl_kmer ? 1 : 0;
+    v->dfl_norestart = c->dfl_norestart ? 1 : 0;
     return SNK_OK;
 }
 int snk_internal_fail(snk_ctx *c, int code, const char *msg) { return fail(c, code, "%s", msg); }
@@ -447,6 +448,8 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         c->dfl_serial = value != 0;
     } else if (k == "deflate_kmer") {
         c->dfl_kmer = value != 0;
+    } else if (k == "deflate_norestart") {
+        c->dfl_norestart = value != 0;
     } else if (k == "content_size") {
         if (c->n) return fail(c, SNK_E_STATE, "content_size must be set before snk_upload");
         c->header_bytes = value ? 15u : 7u;

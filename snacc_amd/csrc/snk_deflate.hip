@@ -101,6 +101,7 @@ DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
     T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
     T.seg_sym = s->d_seg_sym; T.seg_pos = s->d_seg_pos; T.seg_cnt = s->d_seg_cnt;
     T.k_occ = s->d_kocc; T.k_r3 = s->d_kr3; T.k_bstart = s->d_kbstart; T.k_occ8 = s->d_kocc8; T.k_inv2 = s->d_kinv2;
+    T.norestart = v.dfl_norestart ? 1u : 0u;
     T.use_k = (v.dfl_kmer && level == 9 && s->kindexed) ? 1u : 0u;   // pays off only for the 4096-member budget
     level_config(level, T);
     return T;

@@ -64,6 +64,7 @@ struct DflTables {
     const uint32_t *k_occ, *k_r3, *k_bstart;  // position, its rank in the 3-byte bucket; k_bstart: 65537 per sequence
     const uint64_t *k_occ8, *k_inv2;          // the 8 bytes there; per position: index in k_occ | rank in its bucket
     uint32_t use_k;
+    uint32_t norestart;                       // option "deflate_norestart": pair jobs parse x from its start (testing)
     uint32_t *sym, *pos;
     uint64_t *cumbits;
     uint32_t *rhist;                         // 320 counters per sequence: open block at the restart point
@@ -548,7 +549,7 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 
     w.keep_blocks = keep_blocks;
     uint32_t p;
-    const bool restart = mode == 0u && sx.unsafe == 0u && sx.rk != 0u;
+    const bool restart = mode == 0u && sx.unsafe == 0u && sx.rk != 0u && T.norestart == 0u;
     if (restart) {
         for (uint32_t i = lane; i < DFL_HIST; i += 64u) w.L.hist[i] = T.rhist[(size_t)job.xi * DFL_HIST + i];
         const uint32_t blocks_before = sx.rkb / DFL_BLOCK_SYMS;

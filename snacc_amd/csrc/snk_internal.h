@@ -15,6 +15,7 @@ struct SnkSeqView {
     const uint32_t *boff;     // host: byte offset of each in d_bytes (zero padded behind)
     const uint8_t *d_bytes;   // device: the ASCII arena
     int dfl_kmer;             // option "deflate_kmer" (default 1): use the six-byte index in the match search
+    int dfl_norestart;        // option "deflate_norestart": pair jobs do not restart from x's stored stream (testing)
     int dfl_serial;           // option "deflate_serial": per-sequence pass by one wave per sequence (testing)
 };
 

@@ -137,6 +137,36 @@ def test_six_byte_index_on_and_off_agree(hip, oracle_mod):
         assert int(pa[i, j]) == len(gzip.compress(raw[i] + raw[j])), (i, j)
 
 
+def test_pairs_with_and_without_the_x_prefix_restart_agree(hip, oracle_mod):
+    """A pair job normally restarts from x's stored stream ~600 bytes before the seam (and falls back to parsing x
+    from its first byte when a stored-block decision of x could depend on the stream length).  Both ways, same sizes."""
+    rng = np.random.default_rng(41)
+    seqs = [oracle_mod.lcg_genome(85, 150000), oracle_mod.lcg_genome(86, 40000), rng.integers(0, 256, 70000, dtype=np.uint8),
+            np.concatenate([rng.integers(0, 256, 30000, dtype=np.uint8), oracle_mod.lcg_genome(87, 60000)]),
+            np.tile(oracle_mod.lcg_genome(88, 3000), 30)]
+    with hip.HipContext(0) as a, hip.HipContext(0, deflate_norestart=1) as b:
+        a.upload(seqs)
+        b.upload(seqs)
+        for alg in ("gzip", "zlib"):
+            pa, pb = a.deflate_pairs(alg), b.deflate_pairs(alg)
+            assert np.array_equal(pa, pb), (alg, np.argwhere(pa != pb)[:4])
+    raw = [_b(s) for s in seqs]
+    assert int(pb[0, 2]) == len(zlib.compress(raw[0] + raw[2])) and int(pb[3, 1]) == len(zlib.compress(raw[3] + raw[1]))
+
+
+def test_argument_and_state_errors(hip):
+    with hip.HipContext(0) as ctx:
+        with pytest.raises(hip.HipBackendError):
+            ctx.deflate_singles("gzip")                     # nothing uploaded
+        ctx.upload([b"ACGT" * 100, b"GATTACA" * 50])
+        out = np.zeros(2, dtype=np.uint32)
+        assert ctx._L.snk_deflate_singles(ctx._h, 5, out.ctypes.data) == -1       # SNK_E_ARG: only levels 9 and 6
+        assert ctx._L.snk_deflate_pairs(ctx._h, 9, 0, 3, out.ctypes.data) == -1   # row range out of bounds
+        bad = np.array([[0, 2]], dtype=np.int32)
+        assert ctx._L.snk_deflate_pairs_list(ctx._h, 9, 1, bad.ctypes.data, out.ctypes.data) == -1
+        assert [int(v) for v in ctx.deflate_singles("gzip")] == [len(gzip.compress(b"ACGT" * 100)), len(gzip.compress(b"GATTACA" * 50))]
+
+
 def test_pair_lists_tiles_and_single_items(hip, oracle_mod):
     seqs = [oracle_mod.lcg_genome(60 + i, 66000 + 7777 * i) for i in range(7)]
     with hip.HipContext(0) as ctx:
