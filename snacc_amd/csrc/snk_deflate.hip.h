@@ -712,6 +712,7 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
                     bool ok[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
+                        if (j0 + 64u * (uint32_t)u >= lim) { ok[u] = false; len8[u] = 0u; q[u] = 0u; continue; }   // (uniform)
                         const uint32_t j = j0 + 64u * (uint32_t)u + lane;
                         const bool in = j < lim;
                         const bool fromy = j < ny;
