@@ -7,10 +7,11 @@ Same three functions, same signatures and error behaviour:
 * :func:`compute_distance`   -- ref:snacc/pairwise_ncd.py:93-111
 
 ``algorithm == "lz4"`` goes to the HIP backend (``libsnacc_hip.so``) -- there is no CPU
-fallback for it.  For the other codecs a single-item call is the stdlib call the reference
-makes.  :func:`all_pairs` is the batched entry the CLI uses instead of N*N single calls; it
-runs on the HIP backend for ``lz4``, ``gzip`` and ``zlib`` and has no CPU
-fallback either.
+fallback for it.  ``gzip`` and ``zlib`` sizes come from the HIP backend as well (SURVEY.md 8f
+N3), unless the compressed bytes themselves are wanted (``save_directory``) or the
+environment says ``SNACC_DEFLATE=stdlib`` (the reference's own call, asked for explicitly);
+``lzma`` and ``bzip2`` are the stdlib calls the reference makes.  :func:`all_pairs` is the
+batched entry the CLI uses instead of N*N single calls (``lz4``, ``gzip``, ``zlib``).
 """
 import bz2
 import gzip
@@ -72,6 +73,12 @@ def compressed_size(sequences, algorithm, reverse_complement=False, save_directo
             return (sequences, sys.getsizeof(compressed_seq))
         n = int(ctx.pairs_list([item])[0]) if len(parts) == 2 else int(ctx.singles()[0])
         return (sequences, n + GETSIZEOF_OVERHEAD)
+
+    if algorithm in ("gzip", "zlib") and not save_directory and os.environ.get("SNACC_DEFLATE", "hip") != "stdlib":
+        ctx = _hip_context()
+        ctx.upload([bytes(p, encoding="utf-8") for p in parts])
+        item = (0, 1) if len(parts) == 2 else (0, -1)
+        return (sequences, int(ctx.deflate_pairs_list(algorithm, [item])[0]) + GETSIZEOF_OVERHEAD)
 
     sequence = bytes("".join(parts), encoding="utf-8")
     if algorithm == "lzma":

@@ -249,6 +249,22 @@ def test_python_batched_api_and_ncd(hip, oracle_mod):
                 assert m[i, j] == exp
 
 
+def test_python_api_single_items(hip, golden, monkeypatch):
+    """compressed_size(path | (path, path), "gzip" | "zlib") -- the reference's granularity -- on the GPU."""
+    from pathlib import Path
+    from snacc_amd import compressed_size
+    monkeypatch.delenv("SNACC_DEFLATE", raising=False)
+    p = Path(__file__).parent / "golden" / "sample_deflate.fa"
+    p.write_text(">derice\nACTGACTAGCTAGCTAACTG\n>sanka\nGCATCGTAGCTAGCTACGAT\n>junior\nCATCGATCGTACGTACGTAG\n>yul\nATCGATCGATCGTACGATCG\n")
+    try:
+        g = golden["sample_fa"]
+        for alg in ("gzip", "zlib"):
+            assert compressed_size(p, alg) == (p, g["sizes_single"][alg])
+            assert compressed_size((p, p), alg) == ((p, p), g["sizes_selfpair"][alg])
+    finally:
+        p.unlink()
+
+
 def test_cli_gzip_csv_equals_reference_cli(hip, golden, oracle_mod, tmp_path, monkeypatch):
     """`snacc <dir> -c gzip` on the HIP backend writes the CSV the reference CLI wrote (golden fixture)."""
     from click.testing import CliRunner

@@ -37,7 +37,8 @@ def test_getsizeof_overhead():
     assert GETSIZEOF_OVERHEAD == 33
 
 
-def test_stdlib_codecs_match_reference(golden, sample_fa):
+def test_stdlib_codecs_match_reference(golden, sample_fa, monkeypatch):
+    monkeypatch.setenv("SNACC_DEFLATE", "stdlib")       # gzip / zlib: the reference's own call, asked for explicitly
     g = golden["sample_fa"]
     for algo in ("gzip", "zlib", "bzip2", "lzma"):
         key, size = compressed_size(sample_fa, algo)
@@ -200,3 +201,13 @@ def test_cli_gzip_defaults_to_the_hip_backend_and_fails_loudly_without_it(tmp_pa
     res = CliRunner().invoke(cli, [str(d), "-o", "o.csv", "-c", "gzip", "--no-show-progress", "--no-log"])
     assert res.exit_code != 0
     assert not (tmp_path / "o.csv").exists()
+
+
+def test_single_item_gzip_needs_the_hip_backend_by_default(sample_fa, monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    monkeypatch.delenv("SNACC_DEFLATE", raising=False)
+    from snacc_amd.hip_backend import HipBackendError
+    with pytest.raises(HipBackendError):
+        compressed_size(sample_fa, "gzip")
