@@ -368,6 +368,238 @@ __device__ void dfl_block_lengths(const DflLds &L, long &opt_len, long &static_l
     opt_len += 3 * ((long)max_blindex + 1) + 5 + 5 + 4;
 }
 
+// ---- the same tree construction for SMALL alphabets (<= 64 used symbols: any DNA or protein block), on arrays
+// held in VGPR lanes: entry i of a "lane array" is lane i of `lo` (i < 64) or lane i - 64 of `hi`; all indices are
+// wave-uniform, every access is one v_readlane / v_writelane, the control flow is scalar and nothing waits for LDS.
+// Leaves are slots 0..m-1 in zlib's heap order (ascending code, forced ones last), internal nodes m..2m-2.
+// zlib's smaller(n, m) -- lower frequency, or equal frequency and depth[n] <= depth[m] -- is key[n] <= key[m]
+// with key = frequency << 8 | depth.
+struct DflLA { uint32_t lo, hi; };
+__device__ __forceinline__ uint32_t la_get(const DflLA &a, uint32_t i)
+{
+    return i < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)a.lo, (int)i)
+                   : (uint32_t)__builtin_amdgcn_readlane((int)a.hi, (int)(i - 64u));
+}
+// (this clang has no writelane builtin; the s_nop covers the "VALU wrote the lane-select SGPR" hazard, which the
+// compiler does not track into inline assembly)
+__device__ __forceinline__ uint32_t dfl_writelane(uint32_t old, uint32_t val, uint32_t lane)
+{
+    const uint32_t sv = (uint32_t)__builtin_amdgcn_readfirstlane((int)val);     // both are wave-uniform already
+    const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane);
+    // one SGPR operand per VALU instruction on this target: the lane select goes through M0
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sv), "s"(sl));   // (M0 is reserved: the compiler sets it right before each of its own uses)
+    return old;
+}
+__device__ __forceinline__ void la_set(DflLA &a, uint32_t i, uint32_t v)
+{
+    if (i < 64u) a.lo = dfl_writelane(a.lo, v, i);
+    else a.hi = dfl_writelane(a.hi, v, i - 64u);
+}
+
+__device__ __forceinline__ void la_pqdownheap(DflLA &heap, const DflLA &key, uint32_t heap_len, uint32_t k)
+{
+    const uint32_t v = la_get(heap, k), kv = la_get(key, v);
+    uint32_t j = k << 1;
+    while (j <= heap_len) {
+        uint32_t hj = la_get(heap, j), kj = la_get(key, hj);
+        if (j < heap_len) {
+            const uint32_t h2 = la_get(heap, j + 1u), k2 = la_get(key, h2);
+            if (k2 <= kj) { j++; hj = h2; kj = k2; }
+        }
+        if (kv <= kj) break;
+        la_set(heap, k, hj);
+        k = j;
+        j <<= 1;
+    }
+    la_set(heap, k, v);
+}
+
+// kind 0 / 1 / 2 as dfl_build_tree.  In: m natural leaves (code[k] ascending in CODE.lo lanes 0..m-1, key[k] =
+// freq << 8), max_code of them (-1 if none).  Out: LEN[slot] for all leaves, the leaf count incl. forced ones in m,
+// returns zlib's max_code.  Adds to opt_len / static_len exactly as build_tree + gen_bitlen do.
+template <int KIND>
+__device__ __forceinline__ int dfl_tree_small(uint32_t &m, int max_code, DflLA &CODE, DflLA &KEY, DflLA &LEN,
+                                              long &opt_len, long &static_len)
+{
+    const uint32_t max_length = KIND == 2 ? 7u : 15u;
+    while (m < 2u) {                                          // zlib forces two codes of non-zero frequency
+        const uint32_t code = max_code < 2 ? (uint32_t)++max_code : 0u;
+        la_set(CODE, m, code);
+        la_set(KEY, m, 1u << 8);
+        m++;
+        opt_len--;
+        if (KIND == 0) static_len -= (long)dfl_static_llen(code);
+        else if (KIND == 1) static_len -= 5;
+    }
+    DflLA HEAP{0u, 0u}, DAD{0u, 0u};
+    uint32_t heap_len = m;
+    // heap[k + 1] = k: lane arrays can be filled by all lanes at once
+    {
+        const uint32_t lane = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        HEAP.lo = lane == 0u ? 0u : lane - 1u;                // entries 1..63 = 0..62
+        HEAP.hi = lane + 63u;                                 // entries 64.. = 63..
+    }
+    for (uint32_t n = heap_len >> 1; n >= 1u; n--) la_pqdownheap(HEAP, KEY, heap_len, n);
+    uint32_t node = m, heap_max = 2u * m;
+    do {
+        const uint32_t n = la_get(HEAP, 1u);
+        la_set(HEAP, 1u, la_get(HEAP, heap_len));
+        heap_len--;
+        la_pqdownheap(HEAP, KEY, heap_len, 1u);
+        const uint32_t mm = la_get(HEAP, 1u);
+        la_set(HEAP, --heap_max, n);
+        la_set(HEAP, --heap_max, mm);
+        const uint32_t kn = la_get(KEY, n), km = la_get(KEY, mm);
+        const uint32_t dn = kn & 255u, dm = km & 255u;
+        la_set(KEY, node, (((kn >> 8) + (km >> 8)) << 8) | ((dn >= dm ? dn : dm) + 1u));
+        la_set(DAD, n, node);
+        la_set(DAD, mm, node);
+        la_set(HEAP, 1u, node);
+        node++;
+        la_pqdownheap(HEAP, KEY, heap_len, 1u);
+    } while (heap_len >= 2u);
+    la_set(HEAP, --heap_max, la_get(HEAP, 1u));
+
+    // gen_bitlen
+    DflLA BLC{0u, 0u};                                        // bl_count[0..15] in lanes 0..15
+    uint32_t overflow = 0, h;
+    la_set(LEN, la_get(HEAP, heap_max), 0u);
+    for (h = heap_max + 1u; h < 2u * m; h++) {
+        const uint32_t n = la_get(HEAP, h);
+        uint32_t bits = la_get(LEN, la_get(DAD, n)) + 1u;
+        if (bits > max_length) { bits = max_length; overflow++; }
+        la_set(LEN, n, bits);
+        if (n >= m) continue;                                 // not a leaf
+        la_set(BLC, bits, la_get(BLC, bits) + 1u);
+        const uint32_t code = la_get(CODE, n), f = la_get(KEY, n) >> 8;
+        uint32_t xbits = 0, slen = 0;
+        if (KIND == 0) { if (code >= 257u) xbits = dfl_lextra(code - 257u); slen = dfl_static_llen(code); }
+        else if (KIND == 1) { xbits = dfl_dextra(code); slen = 5u; }
+        else xbits = code == 16u ? 2u : (code == 17u ? 3u : (code == 18u ? 7u : 0u));
+        opt_len += (long)f * (long)(bits + xbits);
+        if (KIND != 2) static_len += (long)f * (long)(slen + xbits);
+    }
+    if (overflow > 0u) {
+        int ov = (int)overflow;
+        do {
+            uint32_t bits = max_length - 1u;
+            while (la_get(BLC, bits) == 0u) bits--;
+            la_set(BLC, bits, la_get(BLC, bits) - 1u);
+            la_set(BLC, bits + 1u, la_get(BLC, bits + 1u) + 2u);
+            la_set(BLC, max_length, la_get(BLC, max_length) - 1u);
+            ov -= 2;
+        } while (ov > 0);
+        for (uint32_t bits = max_length; bits != 0u; bits--) {
+            uint32_t n = la_get(BLC, bits);
+            while (n != 0u) {
+                const uint32_t mm = la_get(HEAP, --h);
+                if (mm >= m) continue;
+                const uint32_t old = la_get(LEN, mm);
+                if (old != bits) {
+                    opt_len += ((long)bits - (long)old) * (long)(la_get(KEY, mm) >> 8);
+                    la_set(LEN, mm, bits);
+                }
+                n--;
+            }
+        }
+    }
+    return max_code;
+}
+
+// The used symbols of hist[base .. base + count) as leaves of a lane array (all lanes take part).
+// Returns false when there are more than 64 of them.
+__device__ __forceinline__ bool dfl_gather_leaves(const uint32_t *hist, uint32_t count, DflLA &CODE, DflLA &KEY, uint32_t &m, int &max_code)
+{
+    const uint32_t lane = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    m = 0; max_code = -1;
+    for (uint32_t c0 = 0; c0 < count; c0 += 64u) {
+        const uint32_t idx = c0 + lane;
+        const uint32_t f = idx < count ? hist[idx] : 0u;
+        uint64_t mask = __builtin_amdgcn_ballot_w64(f != 0u);
+        if (m + (uint32_t)__builtin_popcountll(mask) > 64u) return false;
+        while (mask) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            la_set(CODE, m, c0 + i);
+            la_set(KEY, m, (uint32_t)__builtin_amdgcn_readlane((int)f, (int)i) << 8);
+            max_code = (int)(c0 + i);
+            m++;
+        }
+    }
+    return true;
+}
+
+// opt_len / static_len of the block in L.hist with the lane-array trees; false if the alphabet is too big for them
+// (the caller then uses dfl_block_lengths).  All lanes call it; the result is wave-uniform.
+__device__ __forceinline__ bool dfl_block_lengths_small(const DflLds &L, uint32_t lane, long &opt_len, long &static_len)
+{
+    DflLA CODE{0u, 0u}, KEY{0u, 0u}, LEN{0u, 0u};
+    uint32_t m; int maxc;
+    if (!dfl_gather_leaves(L.hist, 286u, CODE, KEY, m, maxc)) return false;
+    // the distance counts are needed after the code lengths have overwritten the head of the histogram: take them now
+    const uint32_t dfreq = lane < 30u ? L.hist[DFL_DOFF + lane] : 0u;
+    opt_len = 0; static_len = 0;
+    const int lmax = dfl_tree_small<0>(m, maxc, CODE, KEY, LEN, opt_len, static_len);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < 288u; i += 64u) L.llen[i] = 0;
+    if (lane < 32u) L.dlen[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < m) L.llen[CODE.lo] = (uint8_t)LEN.lo;          // leaf slot = lane (m <= 64)
+    // distance tree
+    {
+        DflLA DC{0u, 0u}, DK{0u, 0u}, DL{0u, 0u};
+        uint32_t dm = 0; int dmaxc = -1;
+        uint64_t mask = __builtin_amdgcn_ballot_w64(dfreq != 0u);
+        while (mask) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            la_set(DC, dm, i);
+            la_set(DK, dm, (uint32_t)__builtin_amdgcn_readlane((int)dfreq, (int)i) << 8);
+            dmaxc = (int)i;
+            dm++;
+        }
+        const int dmax = dfl_tree_small<1>(dm, dmaxc, DC, DK, DL, opt_len, static_len);
+        if (lane < dm) L.dlen[DC.lo] = (uint8_t)DL.lo;
+        __builtin_amdgcn_wave_barrier();
+        // run-length statistics of the two length arrays (zlib's scan_tree), by lane 0, into L.freq[0..19)
+        if (lane == 0) {
+            for (int n = 0; n < 19; n++) L.freq[n] = 0;
+            dfl_scan_tree(L.llen, lmax, L.freq);
+            dfl_scan_tree(L.dlen, dmax, L.freq);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // bit-length tree
+    {
+        DflLA BC{0u, 0u}, BK{0u, 0u}, BL{0u, 0u};
+        const uint32_t bf = lane < 19u ? (uint32_t)L.freq[lane] : 0u;
+        uint32_t bm = 0; int bmaxc = -1;
+        uint64_t mask = __builtin_amdgcn_ballot_w64(bf != 0u);
+        while (mask) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            la_set(BC, bm, i);
+            la_set(BK, bm, (uint32_t)__builtin_amdgcn_readlane((int)bf, (int)i) << 8);
+            bmaxc = (int)i;
+            bm++;
+        }
+        dfl_tree_small<2>(bm, bmaxc, BC, BK, BL, opt_len, static_len);
+        // which of the 19 codes got a length: bit `code` of used
+        const uint64_t used = __builtin_amdgcn_ballot_w64(lane < bm && BL.lo != 0u);
+        uint32_t usedcodes = 0;
+        {
+            uint64_t u = used;
+            while (u) { const uint32_t i = (uint32_t)__builtin_ctzll(u); u &= u - 1ull; usedcodes |= 1u << la_get(BC, i); }
+        }
+        const uint8_t bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int max_blindex;
+        for (max_blindex = 18; max_blindex >= 3; max_blindex--)
+            if (usedcodes >> bl_order[max_blindex] & 1u) break;
+        opt_len += 3 * ((long)max_blindex + 1) + 5 + 5 + 4;
+    }
+    return true;
+}
+
 // Start of zlib's window (stream position of window[0]) when the parser stands at loop top p0.
 // The window slides by 32 KiB at the first loop top where fewer than 262 bytes of look-ahead are
 // left in it; `n` enters because the last, partly filled window slides one byte earlier.
@@ -422,9 +654,10 @@ __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
 {
     unsigned long long tf0 = 0, tf1 = 0; (void)tf0; (void)tf1;
     DFL_T(tf0);
+    long opt_len = 0, static_len = 0;
+    const bool small = dfl_block_lengths_small(w.L, w.lane, opt_len, static_len);
     if (w.lane == 0) {
-        long opt_len, static_len;
-        dfl_block_lengths(w.L, opt_len, static_len);
+        if (!small) dfl_block_lengths(w.L, opt_len, static_len);
         uint32_t opt_lenb = (uint32_t)((opt_len + 3 + 7) >> 3);
         const uint32_t static_lenb = (uint32_t)((static_len + 3 + 7) >> 3);
         if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
@@ -800,7 +1033,7 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     }
 
     DFL_T(t1);
-    const unsigned long long flush_parse = w.t_flush;
+    const unsigned long long flush_parse = w.t_flush; (void)flush_parse;
     if (sync_k != 0xFFFFFFFFu) {
         // ---- y's own symbols from sync_k on, re-cut into this stream's blocks ----
         uint32_t k = sync_k;
