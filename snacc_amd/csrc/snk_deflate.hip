@@ -151,10 +151,10 @@ int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const st
     DCHK(c, hipEventRecord(s->ev0, v.stream));
     const bool seg = jobs[0].mode == 2u;                     // a launch is all segment jobs or none
     const dim3 grid((nj + DFL_WAVES - 1u) / DFL_WAVES), block(64 * DFL_WAVES);
-    if (T.use_k && seg)       hipLaunchKernelGGL((dfl_parse_kernel<true, true>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
-    else if (T.use_k)         hipLaunchKernelGGL((dfl_parse_kernel<true, false>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
-    else if (seg)             hipLaunchKernelGGL((dfl_parse_kernel<false, true>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
-    else                      hipLaunchKernelGGL((dfl_parse_kernel<false, false>), grid, block, DFL_WAVES * L_WAVE, v.stream, T, s->d_jobs, nj, s->d_out);
+    if (T.use_k && seg)       hipLaunchKernelGGL((dfl_parse_kernel_k<true>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
+    else if (T.use_k)         hipLaunchKernelGGL((dfl_parse_kernel_k<false>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
+    else if (seg)             hipLaunchKernelGGL((dfl_parse_kernel<true>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
+    else                      hipLaunchKernelGGL((dfl_parse_kernel<false>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
     DCHK(c, hipGetLastError());
     DCHK(c, hipEventRecord(s->ev1, v.stream));
     if (host_out) {

@@ -19,19 +19,24 @@ constexpr uint32_t DFL_DOFF = 288u;
 constexpr uint32_t DFL_HEAP = 573u;            // 2 * L_CODES + 1
 constexpr uint32_t DFL_WAVES = 4u;             // wavefronts per workgroup
 
-// LDS of one wavefront (bytes)
+// LDS of a workgroup (bytes): per wavefront its symbol histogram; ONE set of the LDS tree-building arrays, used
+// only by blocks with more than 64 distinct literal/length symbols (binary data) and taken under a lock -- DNA
+// and protein blocks build their trees in registers (dfl_tree_small).
+// The saved code lengths live in the wave's histogram memory: by the time they are written the counts they
+// overwrite (literal codes 0..79) have been copied out, and the histogram is rebuilt afterwards.
 constexpr uint32_t L_HIST = 0;                         // u32[320]
-constexpr uint32_t L_HEAP = L_HIST + 4 * DFL_HIST;     // u16[576]
-constexpr uint32_t L_FREQ = L_HEAP + 2 * 576;          // u16[576]
-constexpr uint32_t L_DAD = L_FREQ + 2 * 576;           // u16[576]
-constexpr uint32_t L_LEN = L_DAD + 2 * 576;            // u16[576]
-constexpr uint32_t L_DEPTH = L_LEN + 2 * 576;          // u8[576]
-// the saved code lengths live in the histogram's memory: by the time they are written the counts they
-// overwrite (literal codes 0..79) have been copied into the tree arrays, and the histogram is rebuilt afterwards
 constexpr uint32_t L_LLEN = L_HIST;                    // u8[288]  code lengths of the literal/length tree
 constexpr uint32_t L_DLEN = L_HIST + 288;              // u8[32]   code lengths of the distance tree
-constexpr uint32_t L_MISC = L_DEPTH + 576;             // u32[8]   results of lane 0
-constexpr uint32_t L_WAVE = L_MISC + 32;               // 6496: 4 waves = 25 984 B per workgroup, 6 workgroups per CU
+constexpr uint32_t L_BLF = L_HIST + 4 * DFL_HIST;      // u16[20]  bit-length code counts (scan_tree)
+constexpr uint32_t L_MISC = L_BLF + 40;                // u32[6]   results of lane 0
+constexpr uint32_t L_WAVE = L_MISC + 24;               // 1344 per wavefront
+constexpr uint32_t G_HEAP = DFL_WAVES * L_WAVE;        // u16[576]   shared from here on
+constexpr uint32_t G_FREQ = G_HEAP + 2 * 576;          // u16[576]
+constexpr uint32_t G_DAD = G_FREQ + 2 * 576;           // u16[576]
+constexpr uint32_t G_LEN = G_DAD + 2 * 576;            // u16[576]
+constexpr uint32_t G_DEPTH = G_LEN + 2 * 576;          // u8[576]
+constexpr uint32_t G_LOCK = G_DEPTH + 576;             // u32
+constexpr uint32_t L_GROUP = G_LOCK + 16;              // 10 576 B per workgroup
 
 struct DflSeq {              // one per resident sequence (device + host mirror)
     uint32_t boff, len;
@@ -224,7 +229,8 @@ __device__ __forceinline__ uint32_t dfl_dextra(uint32_t code) { return code < 4u
 __device__ __forceinline__ uint32_t dfl_static_llen(uint32_t n) { return n <= 143u ? 8u : (n <= 255u ? 9u : (n <= 279u ? 7u : 8u)); }
 
 struct DflLds {
-    uint32_t *hist;
+    uint32_t *hist, *lock;
+    uint16_t *blf;            // per wave: bit-length code counts of the small-alphabet path
     uint16_t *heap, *freq, *dad, *len;
     uint8_t *depth, *llen, *dlen;
     uint32_t *misc;
@@ -563,16 +569,16 @@ __device__ __forceinline__ bool dfl_block_lengths_small(const DflLds &L, uint32_
         __builtin_amdgcn_wave_barrier();
         // run-length statistics of the two length arrays (zlib's scan_tree), by lane 0, into L.freq[0..19)
         if (lane == 0) {
-            for (int n = 0; n < 19; n++) L.freq[n] = 0;
-            dfl_scan_tree(L.llen, lmax, L.freq);
-            dfl_scan_tree(L.dlen, dmax, L.freq);
+            for (int n = 0; n < 19; n++) L.blf[n] = 0;
+            dfl_scan_tree(L.llen, lmax, L.blf);
+            dfl_scan_tree(L.dlen, dmax, L.blf);
         }
         __builtin_amdgcn_wave_barrier();
     }
     // bit-length tree
     {
         DflLA BC{0u, 0u}, BK{0u, 0u}, BL{0u, 0u};
-        const uint32_t bf = lane < 19u ? (uint32_t)L.freq[lane] : 0u;
+        const uint32_t bf = lane < 19u ? (uint32_t)L.blf[lane] : 0u;
         uint32_t bm = 0; int bmaxc = -1;
         uint64_t mask = __builtin_amdgcn_ballot_w64(bf != 0u);
         while (mask) {
@@ -657,7 +663,12 @@ __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
     long opt_len = 0, static_len = 0;
     const bool small = dfl_block_lengths_small(w.L, w.lane, opt_len, static_len);
     if (w.lane == 0) {
-        if (!small) dfl_block_lengths(w.L, opt_len, static_len);
+        if (!small) {                                        // big alphabet: the workgroup's LDS tree arrays, one wave at a time
+            while (atomicCAS(w.L.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(8);
+            dfl_block_lengths(w.L, opt_len, static_len);
+            __threadfence_block();
+            atomicExch(w.L.lock, 0u);
+        }
         uint32_t opt_lenb = (uint32_t)((opt_len + 3 + 7) >> 3);
         const uint32_t static_lenb = (uint32_t)((static_len + 3 + 7) >> 3);
         if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
@@ -722,21 +733,23 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
 
 // USE_K: with the six-byte index in the match search (level 9);  SEG: the launch consists of segment jobs (mode 2)
 template <bool USE_K, bool SEG>
-__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(6)))
-dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
+__device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
     extern __shared__ __align__(16) uint8_t dfl_lds[];
     // the wave index is uniform: telling the compiler so moves the whole parser state to SGPRs
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t jid = blockIdx.x * DFL_WAVES + wave;
+    if (threadIdx.x == 0) *(uint32_t *)(dfl_lds + G_LOCK) = 0u;
+    __syncthreads();                                         // (before any wave can leave)
     if (jid >= njobs) return;
     const DflJob job = jobs[jid];
 
     uint8_t *lds = dfl_lds + wave * L_WAVE;
     DflWave w;
-    w.L.hist = (uint32_t *)(lds + L_HIST); w.L.heap = (uint16_t *)(lds + L_HEAP); w.L.freq = (uint16_t *)(lds + L_FREQ);
-    w.L.dad = (uint16_t *)(lds + L_DAD); w.L.len = (uint16_t *)(lds + L_LEN); w.L.depth = lds + L_DEPTH;
-    w.L.llen = lds + L_LLEN; w.L.dlen = lds + L_DLEN; w.L.misc = (uint32_t *)(lds + L_MISC);
+    w.L.hist = (uint32_t *)(lds + L_HIST); w.L.llen = lds + L_LLEN; w.L.dlen = lds + L_DLEN;
+    w.L.blf = (uint16_t *)(lds + L_BLF); w.L.misc = (uint32_t *)(lds + L_MISC);
+    w.L.heap = (uint16_t *)(dfl_lds + G_HEAP); w.L.freq = (uint16_t *)(dfl_lds + G_FREQ); w.L.dad = (uint16_t *)(dfl_lds + G_DAD);
+    w.L.len = (uint16_t *)(dfl_lds + G_LEN); w.L.depth = dfl_lds + G_DEPTH; w.L.lock = (uint32_t *)(dfl_lds + G_LOCK);
     w.lane = lane;
 
     const DflSeq sx = T.seq[job.xi];
@@ -1098,6 +1111,21 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
             }
         }
     }
+}
+
+// The two kernels: with the six-byte index (gzip) the body needs a few more registers and runs best at 7 waves per
+// SIMD; without it (zlib) at 8.  (Measured: 6 / 7 / 8 waves -> gzip 126 / 133 / 118 k, zlib 140 / 153 / 158 k pair-compr/s.)
+template <bool SEG>
+__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(7)))
+dfl_parse_kernel_k(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
+{
+    dfl_parse_body<true, SEG>(T, jobs, njobs, out);
+}
+template <bool SEG>
+__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
+dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
+{
+    dfl_parse_body<false, SEG>(T, jobs, njobs, out);
 }
 
 // Restart record of every sequence: the last clean state at least DFL_RESTART_BACK bytes before
