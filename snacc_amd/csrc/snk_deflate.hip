@@ -10,12 +10,16 @@
 //  * zlib inserts EVERY position into its hash chains at these levels, so the chain of a position
 //    is a pure function of the data: "earlier positions with the same 15-bit hash of 3 bytes, most
 //    recent first".  Per resident sequence a stable radix sort by hash gives that list with random
-//    access (occ / inv / bucket starts); 64 lanes then test 64 chain candidates at once, in chain
-//    order, honouring zlib's chain budget, distance limits, nice-length early exit and
-//    "first longest wins".
+//    access (occ / inv2 / bucket starts, plus the 8 bytes at every listed position); a wave then tests up
+//    to 256 chain candidates per step, in chain order, honouring zlib's chain budget, distance limits,
+//    nice-length early exit and "first longest wins".  For level 9 a second list keyed by six bytes
+//    narrows the candidates to the ones that can win.
 //  * one wavefront = one parse job; everything deflate_slow decides (lazy evaluation, TOO_FAR,
 //    block cut every 16383 symbols, stored / static / dynamic choice with zlib's exact
-//    build_tree / gen_bitlen / scan_tree) is done by the wave, the trees by lane 0 in LDS.
+//    build_tree / gen_bitlen / scan_tree) is done by the wave; the trees are built on VGPR lane
+//    arrays with scalar control (small alphabets) or by lane 0 in LDS (more than 64 used symbols).
+//  * the same argument as below parallelises the per-sequence pass: 32 KiB segments, stitched where
+//    two parsers provably agree.
 //  * exact work elision: a match can reach back 32 506 bytes only, so the symbol stream of x+y
 //    equals x's own stream until just before the seam and y's own stream from the first point,
 //    at least 32 507 bytes after the seam, where both parsers stand right behind a match ending
