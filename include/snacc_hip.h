@@ -159,7 +159,12 @@ int snk_deflate_prepare(snk_ctx *ctx, int level);
 int snk_deflate_singles(snk_ctx *ctx, int level, uint32_t *sizes /* [n_seq], host */);
 int snk_deflate_pairs(snk_ctx *ctx, int level, int row_begin, int row_end, uint32_t *sizes /* host */);
 int snk_deflate_pairs_list(snk_ctx *ctx, int level, int n_pairs, const int32_t *ij, uint32_t *sizes /* host */);
-/* Device time (ms) of the kernels of the last snk_deflate_pairs / snk_deflate_pairs_list call; < 0 if unavailable. */
+/* Same as snk_deflate_pairs, asynchronous (cf. snk_pairs_device): launches on `hip_stream` (NULL = the context's
+ * stream) and writes the u32 raw stream sizes to DEVICE memory d_sizes ((row_end - row_begin) * n_seq elements),
+ * e.g. a torch tensor that is then all-gathered over RCCL.  Does not synchronise (snk_sync); one stream at a time. */
+int snk_deflate_pairs_device(snk_ctx *ctx, int level, int row_begin, int row_end, void *d_sizes, void *hip_stream);
+/* Device time (ms) of the kernels of the last snk_deflate_pairs / _pairs_list / _pairs_device call (waits for the
+ * launch of an asynchronous call to finish); < 0 if unavailable. */
 double snk_deflate_last_ms(snk_ctx *ctx);
 
 #ifdef __cplusplus

@@ -128,13 +128,12 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
         if deflate and world > 1:
             import torch
             import torch.distributed as dist
-            from .distributed import all_pairs_sharded
+            from .distributed import all_pairs_deflate_hip
             torch.cuda.set_device(ctx.device)
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device))
-            pairs = all_pairs_sharded(n, lambda r0, r1: ctx.deflate_pairs(algorithm, r0, r1),
-                                      device=torch.device("cuda", ctx.device)).astype(np.int64) + GETSIZEOF_OVERHEAD
+            pairs = all_pairs_deflate_hip(ctx, n, algorithm).astype(np.int64) + GETSIZEOF_OVERHEAD
         elif deflate:
             tile = max(1, (1 << 18) // max(n, 1))
             starts = range(0, n, tile)

@@ -63,6 +63,7 @@ struct DflState {
     int n_serial = 0;                     // sequences of the last per-sequence pass that needed the serial parse
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = -1.0;               // device time of the parse kernels of the last pairs call
+    bool pending = false;                // an asynchronous launch whose event pair has not been read yet
 };
 
 template <typename P> void dfree(P *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
@@ -143,31 +144,61 @@ int dfl_ensure_scratch(snk_ctx *c, DflState *s, size_t njobs)
     return SNK_OK;
 }
 
+// Launch nj jobs that are already in s->d_jobs, on `stream`, results to d_out (device).  Brackets the kernel with
+// the state's event pair; does not synchronise.
+int dfl_launch_dev(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, uint32_t nj, bool seg, hipStream_t stream, uint32_t *d_out)
+{
+    const DflTables T = make_tables(s, v, level);
+    if (!s->ev0) { DCHK(c, hipEventCreate(&s->ev0)); DCHK(c, hipEventCreate(&s->ev1)); }
+    DCHK(c, hipEventRecord(s->ev0, stream));
+    const dim3 grid((nj + DFL_WAVES - 1u) / DFL_WAVES), block(64 * DFL_WAVES);
+    if (T.use_k && seg)       hipLaunchKernelGGL((dfl_parse_kernel_k<true>), grid, block, L_GROUP, stream, T, s->d_jobs, nj, d_out);
+    else if (T.use_k)         hipLaunchKernelGGL((dfl_parse_kernel_k<false>), grid, block, L_GROUP, stream, T, s->d_jobs, nj, d_out);
+    else if (seg)             hipLaunchKernelGGL((dfl_parse_kernel<true>), grid, block, L_GROUP, stream, T, s->d_jobs, nj, d_out);
+    else                      hipLaunchKernelGGL((dfl_parse_kernel<false>), grid, block, L_GROUP, stream, T, s->d_jobs, nj, d_out);
+    DCHK(c, hipGetLastError());
+    DCHK(c, hipEventRecord(s->ev1, stream));
+    return SNK_OK;
+}
+
+int dfl_add_elapsed(DflState *s)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = (s->last_ms < 0 ? 0.0 : s->last_ms) + (double)ms;
+    return SNK_OK;
+}
+
 int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const std::vector<DflJob> &jobs, uint32_t *host_out)
 {
     if (jobs.empty()) return SNK_OK;
     int rc = dfl_ensure_scratch(c, s, jobs.size());
     if (rc != SNK_OK) return rc;
     DCHK(c, hipMemcpyAsync(s->d_jobs, jobs.data(), jobs.size() * sizeof(DflJob), hipMemcpyHostToDevice, v.stream));
-    const DflTables T = make_tables(s, v, level);
-    const uint32_t nj = (uint32_t)jobs.size();
-    if (!s->ev0) { DCHK(c, hipEventCreate(&s->ev0)); DCHK(c, hipEventCreate(&s->ev1)); }
-    DCHK(c, hipEventRecord(s->ev0, v.stream));
-    const bool seg = jobs[0].mode == 2u;                     // a launch is all segment jobs or none
-    const dim3 grid((nj + DFL_WAVES - 1u) / DFL_WAVES), block(64 * DFL_WAVES);
-    if (T.use_k && seg)       hipLaunchKernelGGL((dfl_parse_kernel_k<true>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
-    else if (T.use_k)         hipLaunchKernelGGL((dfl_parse_kernel_k<false>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
-    else if (seg)             hipLaunchKernelGGL((dfl_parse_kernel<true>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
-    else                      hipLaunchKernelGGL((dfl_parse_kernel<false>), grid, block, L_GROUP, v.stream, T, s->d_jobs, nj, s->d_out);
-    DCHK(c, hipGetLastError());
-    DCHK(c, hipEventRecord(s->ev1, v.stream));
+    rc = dfl_launch_dev(c, s, v, level, (uint32_t)jobs.size(), jobs[0].mode == 2u, v.stream, s->d_out);   // a launch is all segment jobs or none
+    if (rc != SNK_OK) return rc;
     if (host_out) {
         DCHK(c, hipMemcpyAsync(host_out, s->d_out, jobs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
     }
     DCHK(c, hipStreamSynchronize(v.stream));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = (s->last_ms < 0 ? 0.0 : s->last_ms) + (double)ms;
-    return SNK_OK;
+    return dfl_add_elapsed(s);
+}
+
+// Rows [r0, r1) x all columns: the job list is written by a kernel, nothing but the sizes crosses the bus.
+int dfl_launch_rows(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, size_t r0, size_t r1, hipStream_t stream, uint32_t *d_out)
+{
+    const size_t nj = (r1 - r0) * (size_t)v.n;
+    if (nj == 0) return SNK_OK;
+    if (nj > 0xFFFFFFF0ull) return snk_internal_fail(c, SNK_E_ARG, "too many pairs in one call");
+    if (nj > s->jobs_cap) {
+        DCHK(c, hipStreamSynchronize(stream));
+        dfree(s->d_jobs);
+        DCHK(c, hipMalloc((void **)&s->d_jobs, nj * sizeof(DflJob)));
+        s->jobs_cap = nj;
+    }
+    hipLaunchKernelGGL(dfl_rowjobs_kernel, dim3((uint32_t)std::min<size_t>((nj + 255) / 256, 8192)), dim3(256), 0, stream,
+                       s->d_jobs, (uint32_t)r0, (uint32_t)(r1 - r0), (uint32_t)v.n);
+    DCHK(c, hipGetLastError());
+    return dfl_launch_dev(c, s, v, level, (uint32_t)nj, false, stream, d_out);
 }
 
 int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
@@ -447,19 +478,37 @@ int snk_deflate_pairs(snk_ctx *c, int level, int row_begin, int row_end, uint32_
     if (row_begin < 0 || row_end > v.n || row_begin > row_end) return snk_internal_fail(c, SNK_E_ARG, "row range out of bounds");
     const size_t n = (size_t)v.n;
     s->last_ms = -1.0;
-    // in tiles, so that the job list stays small
+    // in tiles of about a million pairs
     const size_t tile_rows = std::max<size_t>(1, (size_t)(1u << 20) / n);
-    std::vector<DflJob> jobs;
     for (size_t r0 = (size_t)row_begin; r0 < (size_t)row_end; r0 += tile_rows) {
         const size_t r1 = std::min<size_t>((size_t)row_end, r0 + tile_rows);
-        jobs.resize((r1 - r0) * n);
-        for (size_t i = r0; i < r1; ++i)
-            for (size_t j = 0; j < n; ++j)
-                jobs[(i - r0) * n + j] = DflJob{(int32_t)i, (int32_t)j, 0u, (uint32_t)((i - r0) * n + j), 0u, 0u, 0ull};
-        rc = dfl_launch(c, s, v, level, jobs, sizes + (r0 - (size_t)row_begin) * n);
+        const size_t nj = (r1 - r0) * n;
+        if (nj > s->out_cap) {
+            dfree(s->d_out);
+            DCHK(c, hipMalloc((void **)&s->d_out, nj * sizeof(uint32_t)));
+            s->out_cap = nj;
+        }
+        rc = dfl_launch_rows(c, s, v, level, r0, r1, v.stream, s->d_out);
         if (rc != SNK_OK) return rc;
+        DCHK(c, hipMemcpyAsync(sizes + (r0 - (size_t)row_begin) * n, s->d_out, nj * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
+        DCHK(c, hipStreamSynchronize(v.stream));
+        dfl_add_elapsed(s);
     }
     return SNK_OK;
+}
+
+/* Same, asynchronous: rows [row_begin, row_end) on `hip_stream` (NULL = the context's stream), u32 raw stream
+ * sizes to DEVICE memory d_sizes ((row_end - row_begin) * n_seq elements); no synchronisation (snk_sync). */
+int snk_deflate_pairs_device(snk_ctx *c, int level, int row_begin, int row_end, void *d_sizes, void *hip_stream)
+{
+    if (!c || !d_sizes) return c ? snk_internal_fail(c, SNK_E_ARG, "d_sizes is NULL") : SNK_E_ARG;
+    SnkSeqView v; DflState *s = nullptr;
+    int rc = dfl_prepare(c, level, v, s);
+    if (rc != SNK_OK) return rc;
+    if (row_begin < 0 || row_end > v.n || row_begin > row_end) return snk_internal_fail(c, SNK_E_ARG, "row range out of bounds");
+    s->last_ms = -1.0;
+    s->pending = true;
+    return dfl_launch_rows(c, s, v, level, (size_t)row_begin, (size_t)row_end, hip_stream ? (hipStream_t)hip_stream : v.stream, (uint32_t *)d_sizes);
 }
 
 int snk_deflate_pairs_list(snk_ctx *c, int level, int n_pairs, const int32_t *ij, uint32_t *sizes)
@@ -484,7 +533,14 @@ double snk_deflate_last_ms(snk_ctx *c)
 {
     if (!c) return -1.0;
     void **slot = snk_internal_dfl_slot(c, nullptr);
-    return *slot ? ((DflState *)*slot)->last_ms : -1.0;
+    DflState *s = (DflState *)*slot;
+    if (!s) return -1.0;
+    if (s->pending && s->ev1) {                           // asynchronous launch: valid once its stream has been synchronised
+        if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.0;
+        s->pending = false;
+        dfl_add_elapsed(s);
+    }
+    return s->last_ms;
 }
 
 }  // extern "C"

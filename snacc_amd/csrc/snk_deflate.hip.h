@@ -1128,6 +1128,18 @@ dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
     dfl_parse_body<false, SEG>(T, jobs, njobs, out);
 }
 
+// Job list of a row tile, made on the device: job t = pair (r0 + t / n, t % n), result slot t.
+__global__ void dfl_rowjobs_kernel(DflJob *jobs, uint32_t r0, uint32_t nrows, uint32_t n)
+{
+    const uint64_t total = (uint64_t)nrows * n;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        DflJob j;
+        j.xi = (int32_t)(r0 + (uint32_t)(t / n)); j.yi = (int32_t)(t % n);
+        j.mode = 0u; j.out_idx = (uint32_t)t; j.p0 = 0u; j.p1 = 0u; j.aux = 0ull;
+        jobs[t] = j;
+    }
+}
+
 // Restart record of every sequence: the last clean state at least DFL_RESTART_BACK bytes before
 // its end, and the symbol counts of the block that is open there.  One wave per sequence.
 __global__ void __launch_bounds__(64) dfl_restart_kernel(DflTables T, uint32_t nseq)

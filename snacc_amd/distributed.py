@@ -68,3 +68,23 @@ def all_pairs_hip(ctx, n, group=None):
         return out
 
     return all_pairs_sharded(n, rows_fn, group=group, device=dev)
+
+
+def all_pairs_deflate_hip(ctx, n, algorithm, group=None):
+    """Sharded phase B of the gzip / zlib path: as :func:`all_pairs_hip`, sizes include the wrapper bytes."""
+    import torch
+    from .hip_backend import DEFLATE
+
+    dev = torch.device("cuda", ctx.device)
+
+    def rows_fn(r0, r1):
+        out = torch.zeros((max(r1 - r0, 0), n), dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        tile = max(1, min(r1 - r0, (1 << 20) // max(n, 1)))
+        for t0 in range(r0, r1, tile):
+            t1 = min(r1, t0 + tile)
+            ctx.deflate_pairs_device(algorithm, t0, t1, out.data_ptr() + (t0 - r0) * n * 4, None)
+            ctx.sync(None)
+        return out
+
+    return all_pairs_sharded(n, rows_fn, group=group, device=dev) + np.uint32(DEFLATE[algorithm][1])

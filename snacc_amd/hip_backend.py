@@ -22,7 +22,7 @@ EXPORTS = (
     "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
-    "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_last_ms",
+    "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_pairs_device", "snk_deflate_last_ms",
 )
 
 #: deflate level and wrapper bytes behind the reference's gzip / zlib choices
@@ -122,6 +122,8 @@ def load():
     L.snk_deflate_pairs.argtypes = [vp, i32, i32, i32, vp]
     L.snk_deflate_pairs_list.restype = i32
     L.snk_deflate_pairs_list.argtypes = [vp, i32, i32, vp, vp]
+    L.snk_deflate_pairs_device.restype = i32
+    L.snk_deflate_pairs_device.argtypes = [vp, i32, i32, i32, vp, vp]
     L.snk_deflate_last_ms.restype = ctypes.c_double
     L.snk_deflate_last_ms.argtypes = [vp]
     if L.snk_version() != ABI_VERSION:
@@ -305,6 +307,13 @@ class HipContext:
         self._check(self._L.snk_deflate_pairs_list(self._h, level, len(ij), ij.ctypes.data, out.ctypes.data),
                     "snk_deflate_pairs_list")
         return out + np.uint32(wrapper)
+
+    def deflate_pairs_device(self, algorithm, row_begin, row_end, d_ptr, stream=None):
+        """Asynchronous rows [row_begin, row_end): RAW deflate stream sizes (no wrapper bytes) as u32 to device
+        memory at `d_ptr`, launched on `stream` (a hipStream_t as int; None = the context's stream)."""
+        level, _ = DEFLATE[algorithm]
+        self._check(self._L.snk_deflate_pairs_device(self._h, level, row_begin, row_end, ctypes.c_void_p(d_ptr),
+                                                     ctypes.c_void_p(stream) if stream else None), "snk_deflate_pairs_device")
 
     def deflate_last_ms(self):
         return float(self._L.snk_deflate_last_ms(self._h))

@@ -154,6 +154,32 @@ def test_pairs_with_and_without_the_x_prefix_restart_agree(hip, oracle_mod):
     assert int(pb[0, 2]) == len(zlib.compress(raw[0] + raw[2])) and int(pb[3, 1]) == len(zlib.compress(raw[3] + raw[1]))
 
 
+def test_device_output_rows_equal_host_rows(hip, oracle_mod):
+    import torch
+    seqs = [oracle_mod.lcg_genome(120 + i, 60000 + 9000 * i) for i in range(6)]
+    dev = torch.device("cuda", 0)
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        for alg, wrapper in (("gzip", 18), ("zlib", 6)):
+            host = ctx.deflate_pairs(alg, 1, 5)
+            out = torch.zeros((4, 6), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            ctx.deflate_pairs_device(alg, 1, 5, out.data_ptr())
+            ctx.sync()
+            assert ctx.deflate_last_ms() > 0
+            assert np.array_equal(out.cpu().numpy().view(np.uint32) + np.uint32(wrapper), host)
+            stream = torch.cuda.Stream(dev)
+            out2 = torch.zeros((6, 6), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            ctx.deflate_pairs_device(alg, 0, 6, out2.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            assert np.array_equal(out2.cpu().numpy().view(np.uint32)[1:5] + np.uint32(wrapper), host)
+    from snacc_amd.distributed import all_pairs_deflate_hip
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert np.array_equal(all_pairs_deflate_hip(ctx, 6, "zlib")[1:5], host)        # world size 1: no collective
+
+
 def test_argument_and_state_errors(hip):
     with hip.HipContext(0) as ctx:
         with pytest.raises(hip.HipBackendError):
