@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnacc_hip.so")
+#: the in-tree library; SNACC_HIP_LIB points the binding at another build of it (development A/B runs)
+LIB_PATH = os.environ.get("SNACC_HIP_LIB") or os.path.join(_HERE, "libsnacc_hip.so")
 ABI_VERSION = 1
 
 #: every symbol ``include/snacc_hip.h`` declares (checked by the CPU test-suite)
