@@ -54,7 +54,7 @@ struct DflState {
     uint64_t *d_occ8 = nullptr, *d_inv2 = nullptr;
     uint32_t *d_kocc = nullptr, *d_kr3 = nullptr, *d_kbstart = nullptr;
     uint64_t *d_kocc8 = nullptr, *d_kinv2 = nullptr;
-    uint32_t *d_sym = nullptr, *d_pos = nullptr, *d_rhist = nullptr, *d_status = nullptr;
+    uint32_t *d_sym = nullptr, *d_pos = nullptr, *d_rhist = nullptr, *d_status = nullptr, *d_chk = nullptr;
     uint64_t *d_cumbits = nullptr;
     DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
     uint32_t *d_out = nullptr; size_t out_cap = 0;
@@ -76,7 +76,7 @@ void dfl_destroy(void *v)
     dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart);
     dfree(s->d_kocc); dfree(s->d_kr3); dfree(s->d_kbstart); dfree(s->d_kocc8); dfree(s->d_kinv2); dfree(s->d_sym); dfree(s->d_pos);
     dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
-    dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt);
+    dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt); dfree(s->d_chk);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -106,6 +106,7 @@ DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
     T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
     T.seg_sym = s->d_seg_sym; T.seg_pos = s->d_seg_pos; T.seg_cnt = s->d_seg_cnt;
     T.k_occ = s->d_kocc; T.k_r3 = s->d_kr3; T.k_bstart = s->d_kbstart; T.k_occ8 = s->d_kocc8; T.k_inv2 = s->d_kinv2;
+    T.chk = s->d_chk;
     T.norestart = v.dfl_norestart ? 1u : 0u;
     T.use_k = (v.dfl_kmer && level == 9 && s->kindexed) ? 1u : 0u;   // pays off only for the 4096-member budget
     level_config(level, T);
@@ -322,6 +323,7 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     if (level == 9 && v.dfl_kmer && !s->kindexed) { rc = dfl_build_kindex(c, s, v); if (rc != SNK_OK) return rc; }
     if (s->level == level) return SNK_OK;
     // stand-alone stream of every sequence at this level
+    dfree(s->d_chk);
     for (auto &q : s->seq) { q.nsym = 0; q.unsafe = 0; q.total_bits = 0; q.rk = q.rpos = q.rkb = q.rbpos = 0; }
     // (every copy and memset below is ordered on v.stream: the kernels run there, and it does not synchronise
     // with the null stream)
@@ -422,6 +424,19 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     DCHK(c, hipMemcpyAsync(s->seq.data(), s->d_seq, s->seq.size() * sizeof(DflSeq), hipMemcpyDeviceToHost, v.stream));
     DCHK(c, hipStreamSynchronize(v.stream));
     for (int g = 0; g < v.n; ++g) s->single[(size_t)g] = (uint32_t)(s->seq[(size_t)g].total_bits >> 3);
+    // cumulative code counts at every 128th symbol of every stored stream: a pair job prices y's blocks from two
+    // checkpoints and at most 254 symbols instead of streaming all of y's symbols
+    {
+        uint64_t ktot = 0;
+        for (auto &q : s->seq) { q.koff = ktot; ktot += ((uint64_t)q.nsym / DFL_CHK + 1u) * DFL_HIST; }
+        dfree(s->d_chk);
+        DCHK(c, hipMalloc((void **)&s->d_chk, ktot * 4));
+        DCHK(c, hipMemcpyAsync(s->d_seq, s->seq.data(), s->seq.size() * sizeof(DflSeq), hipMemcpyHostToDevice, v.stream));
+        DflTables Tc = make_tables(s, v, level);
+        hipLaunchKernelGGL(dfl_chk_kernel, dim3((uint32_t)v.n), dim3(64), 0, v.stream, Tc, s->d_chk, (uint32_t)v.n);
+        DCHK(c, hipGetLastError());
+        DCHK(c, hipStreamSynchronize(v.stream));
+    }
     s->level = level;
     return SNK_OK;
 }

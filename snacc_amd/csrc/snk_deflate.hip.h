@@ -46,6 +46,7 @@ struct DflSeq {              // one per resident sequence (device + host mirror)
     uint32_t nsym;           // symbols of the stand-alone stream
     uint32_t unsafe;         // 1: a stored-block decision near the end depends on the total length
     uint64_t total_bits;
+    uint64_t koff;           // element offset into chk (checkpoint c of this sequence at koff + 320 * c)
     uint32_t rk, rpos;       // restart point: symbol index (clean state) and its stream position
     uint32_t rkb, rbpos;     // first symbol / stream position of the block that is open at rk
 };
@@ -74,6 +75,7 @@ struct DflTables {
     uint64_t *cumbits;
     uint32_t *rhist;                         // 320 counters per sequence: open block at the restart point
     uint32_t *seg_sym, *seg_pos, *seg_cnt;   // scratch streams of the segment jobs, and their symbol counts
+    const uint32_t *chk;                     // per sequence, per 128 symbols: counts of every code in the symbols before (320 each)
     uint32_t good, lazy, nice, chain;
     uint32_t *status;
 };
@@ -731,6 +733,55 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
     }
 }
 
+// Add the symbols [a, b) of a stored stream to the wave's histogram: whole 128-symbol chunks as the difference of
+// two checkpoints (each lane owns five histogram entries), the ragged ends symbol by symbol.
+constexpr uint32_t DFL_CHK = 128u;
+__device__ __forceinline__ void dfl_hist_scan(uint32_t *hist, const uint32_t *sym, uint32_t a, uint32_t b, uint32_t lane)
+{
+    for (uint32_t i = a + lane; i < b; i += 64u) {
+        const uint32_t sv = sym[i];
+        if (sv >> 31) {
+            atomicAdd(&hist[257u + dfl_lcode((sv >> 16) & 0x7fffu)], 1u);
+            atomicAdd(&hist[DFL_DOFF + dfl_dcode((sv & 0xffffu) - 1u)], 1u);
+        } else {
+            atomicAdd(&hist[sv], 1u);
+        }
+    }
+}
+__device__ __forceinline__ void dfl_hist_add_range(uint32_t *hist, const uint32_t *sym, const uint32_t *chk, uint32_t a, uint32_t b, uint32_t lane)
+{
+    const uint32_t ca = (a + DFL_CHK - 1u) / DFL_CHK, cb = b / DFL_CHK;
+    if (ca >= cb) { dfl_hist_scan(hist, sym, a, b, lane); return; }
+    dfl_hist_scan(hist, sym, a, ca * DFL_CHK, lane);
+    dfl_hist_scan(hist, sym, cb * DFL_CHK, b, lane);
+    const uint32_t *pa = chk + (size_t)ca * DFL_HIST, *pb = chk + (size_t)cb * DFL_HIST;
+    for (uint32_t i = lane; i < DFL_HIST; i += 64u) {
+        const uint32_t d = pb[i] - pa[i];
+        if (d) atomicAdd(&hist[i], d);
+    }
+}
+
+// Checkpoints of one sequence's stored stream.  One wave per sequence.
+__global__ void __launch_bounds__(64) dfl_chk_kernel(DflTables T, uint32_t *chk_rw, uint32_t nseq)
+{
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    if (g >= nseq) return;
+    __shared__ uint32_t hist[DFL_HIST];
+    const DflSeq q = T.seq[g];
+    const uint32_t *sym = T.sym + q.soff;
+    uint32_t *out = chk_rw + q.koff;
+    for (uint32_t i = lane; i < DFL_HIST; i += 64u) hist[i] = 0u;
+    __syncthreads();
+    const uint32_t nchk = q.nsym / DFL_CHK + 1u;
+    for (uint32_t c = 0; c < nchk; ++c) {
+        for (uint32_t i = lane; i < DFL_HIST; i += 64u) out[(size_t)c * DFL_HIST + i] = hist[i];
+        __syncthreads();
+        const uint32_t a = c * DFL_CHK, b = a + DFL_CHK < q.nsym ? a + DFL_CHK : q.nsym;
+        dfl_hist_scan(hist, sym, a, b, lane);
+        __syncthreads();
+    }
+}
+
 // USE_K: with the six-byte index in the match search (level 9);  SEG: the launch consists of segment jobs (mode 2)
 template <bool USE_K, bool SEG>
 __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
@@ -1051,32 +1102,16 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
         // ---- y's own symbols from sync_k on, re-cut into this stream's blocks ----
         uint32_t k = sync_k;
         __builtin_amdgcn_wave_barrier();
+        const uint32_t *chky = (mode == 0u && T.chk) ? T.chk + sy.koff : nullptr;
         while (k < ynsym) {
             uint32_t m = ynsym - k;
-            if (m > 128u) m = 128u;                               // two symbols per lane, their loads in flight together
+            if (!chky && m > 128u) m = 128u;                      // without checkpoints: two symbols per lane at a time
             if (m > DFL_BLOCK_SYMS - w.bcount) m = DFL_BLOCK_SYMS - w.bcount;
-            const uint32_t s0v = lane < m ? symy[k + lane] : 0u;
-            const uint32_t s1v = lane + 64u < m ? symy[k + lane + 64u] : 0u;
-            if (lane < m) {
-                if (s0v >> 31) {
-                    atomicAdd(&w.L.hist[257u + dfl_lcode((s0v >> 16) & 0x7fffu)], 1u);
-                    atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((s0v & 0xffffu) - 1u)], 1u);
-                } else {
-                    atomicAdd(&w.L.hist[s0v], 1u);
-                }
-            }
-            if (lane + 64u < m) {
-                if (s1v >> 31) {
-                    atomicAdd(&w.L.hist[257u + dfl_lcode((s1v >> 16) & 0x7fffu)], 1u);
-                    atomicAdd(&w.L.hist[DFL_DOFF + dfl_dcode((s1v & 0xffffu) - 1u)], 1u);
-                } else {
-                    atomicAdd(&w.L.hist[s1v], 1u);
-                }
-            }
+            if (chky) dfl_hist_add_range(w.L.hist, symy, chky, k, k + m, lane);     // everything up to the block's end at once
+            else dfl_hist_scan(w.L.hist, symy, k, k + m, lane);
             k += m; w.bcount += m; w.nsym += m;
             if (w.bcount == DFL_BLOCK_SYMS) {
-                const uint32_t last = m - 1u;
-                const uint32_t sl = (uint32_t)__shfl((int)(last >= 64u ? s1v : s0v), (int)(last & 63u), 64);
+                const uint32_t sl = symy[k - 1u];
                 const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();
