@@ -116,3 +116,42 @@ def test_golden_deflate_sizes(D, golden, oracle_mod):
     for r in g["other_alphabets"]:
         a = lcg_bytes(r["seed"], r["n"], bytes.fromhex(r["alphabet_hex"]))
         assert (D.gzip_size(a), D.zlib_size(a)) == (r["gzip"], r["zlib"]), r["name"]
+
+
+def _stream(D, x, y=None, level=9):
+    raw, sym, blk = D.trace(x, y, level)
+    ln = np.where(sym >> 31, ((sym >> 16) & 0x7fff) + 3, 1).astype(np.int64)
+    pos = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.int64)
+    return sym, pos
+
+
+@pytest.mark.parametrize("level", [9, 6])
+def test_symbol_stream_of_a_pair_is_x_prefix_seam_y_suffix(D, oracle_mod, level):
+    """The exactness argument of the GPU path, checked on the oracle's own symbol streams:
+    the stream of x+y equals x's stream until shortly before the seam, and y's stream from the first position
+    >= 32 507 bytes behind the seam at which both parsers stand right behind a match ending at the same place."""
+    rng = np.random.default_rng(level)
+    x = oracle_mod.lcg_genome(11, 150000)
+    rel = x[20000:].copy()
+    hit = rng.random(len(rel)) < 0.02
+    rel[hit] = rng.choice(ACGT, int(hit.sum()))
+    for y in (oracle_mod.lcg_genome(12, 120000), rel, _gen(rng, 3, 90000)):
+        lx = len(x)
+        sx, px = _stream(D, x, None, level)
+        sy, py = _stream(D, y, None, level)
+        sp, pp = _stream(D, x, y, level)
+        # x's own stream is a prefix of the pair's, at least up to 600 bytes before the seam (the restart point)
+        k = int(np.searchsorted(px, lx - 600))
+        assert np.array_equal(sx[:k], sp[:k]) and np.array_equal(px[:k], pp[:k])
+        # first common "right behind a match" position at least 32 507 bytes behind the seam
+        pya = py + lx
+        found = None
+        for kp in np.flatnonzero(pp >= lx + 32507):
+            if sp[kp - 1] >> 31:
+                ky = int(np.searchsorted(pya, pp[kp]))
+                if ky < len(pya) and pya[ky] == pp[kp] and ky > 0 and (sy[ky - 1] >> 31):
+                    found = (int(kp), ky)
+                    break
+        assert found is not None and pp[found[0]] < lx + 34000      # on these inputs they meet within a few hundred bytes
+        kp, ky = found
+        assert np.array_equal(sp[kp:], sy[ky:]) and np.array_equal(pp[kp:], pya[ky:])
