@@ -35,6 +35,9 @@ def lib():
         L.dfl_oracle_trace.restype = u64
         L.dfl_oracle_trace.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
                                        ctypes.POINTER(ctypes.c_size_t), vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.dfl_oracle_trace_from.restype = u64
+        L.dfl_oracle_trace_from.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
+                                            ctypes.POINTER(ctypes.c_size_t)]
         L.dfl_oracle_block_bits.restype = u64
         L.dfl_oracle_block_bits.argtypes = [vp, vp]
         _lib = L
@@ -74,6 +77,16 @@ def trace(x, y=None, level=9):
                                b.size if b is not None else 0, level, sym.ctypes.data, sym.size, ctypes.byref(ns),
                                blk.ctypes.data, blk.size, ctypes.byref(nb))
     return int(r), sym[:ns.value], blk[:nb.value]
+
+
+def trace_from(x, start, level=9):
+    """Symbols of a parser that starts at `start` right behind a (fictional) match, all earlier positions in the
+    hash chains (a segment job of the GPU path)."""
+    a = _arr(x)
+    sym = np.zeros(a.size - start + 1, dtype=np.uint32)
+    ns = ctypes.c_size_t(0)
+    lib().dfl_oracle_trace_from(a.ctypes.data, a.size, start, level, sym.ctypes.data, sym.size, ctypes.byref(ns))
+    return sym[:ns.value]
 
 
 def block_bits(lfreq, dfreq):

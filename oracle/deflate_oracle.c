@@ -116,6 +116,8 @@ typedef struct {
     long opt_len, static_len;
     int heap[HEAP_SIZE], heap_len, heap_max;
     uint8_t depth[HEAP_SIZE];
+    size_t abs_pos;          /* stream position of strstart while priming */
+    size_t start;            /* positions before `start` are only inserted into the hash chains (segment jobs) */
     /* result */
     uint64_t bits;
     /* optional trace of the emitted symbols / blocks (debug aid for the GPU port) */
@@ -425,6 +427,13 @@ static void deflate_slow(dfl_state *s)
         }
         hash_head = 0;
         if (s->lookahead >= MIN_MATCH) INSERT_STRING(s, s->strstart, hash_head);
+        if (s->abs_pos < s->start) {                 /* priming: like a preset dictionary, nothing is parsed or emitted */
+            s->strstart++;
+            s->lookahead--;
+            s->abs_pos++;
+            s->block_start = (long)s->strstart;
+            continue;
+        }
         s->prev_length = s->match_length;
         s->prev_match = s->match_start;
         s->match_length = MIN_MATCH - 1;
@@ -511,6 +520,23 @@ uint64_t dfl_oracle_trace(const uint8_t *a, size_t na, const uint8_t *b, size_t 
 /* Block cost alone (the trees.c part): frequencies of the 286 literal/length codes (END_BLOCK
  * included by the caller or not -- it is forced to 1 as zlib does) and of the 30 distance codes
  * -> bits the block adds to the stream when it is not stored, i.e. min(static, dynamic) + 3. */
+/* The symbol stream of a parser that starts at stream position `start` "as if right behind a match", with every
+ * earlier position in the hash chains but nothing parsed before (what a segment job of the GPU path does; zlib
+ * itself behaves like this after deflateSetDictionary).  Symbols as in dfl_oracle_trace. */
+uint64_t dfl_oracle_trace_from(const uint8_t *a, size_t na, size_t start, int level, uint32_t *sym, size_t sym_cap, size_t *n_sym)
+{
+    uint64_t r;
+    dfl_state *s = dfl_new(a, na, NULL, 0, level);
+    if (!s || start > na) { free(s); return 0; }
+    s->start = start;
+    s->sym_trace = sym; s->sym_cap = sym_cap;
+    deflate_slow(s);
+    r = s->bits >> 3;
+    if (n_sym) *n_sym = s->sym_n;
+    free(s);
+    return r;
+}
+
 uint64_t dfl_oracle_block_bits(const uint16_t *lfreq, const uint16_t *dfreq)
 {
     uint64_t r;

@@ -155,3 +155,26 @@ def test_symbol_stream_of_a_pair_is_x_prefix_seam_y_suffix(D, oracle_mod, level)
         assert found is not None and pp[found[0]] < lx + 34000      # on these inputs they meet within a few hundred bytes
         kp, ky = found
         assert np.array_equal(sp[kp:], sy[ky:]) and np.array_equal(pp[kp:], pya[ky:])
+
+
+@pytest.mark.parametrize("level", [9, 6])
+def test_a_parser_started_mid_stream_joins_the_true_stream(D, oracle_mod, level):
+    """The argument behind the parallel per-sequence pass: a parser that starts at position p0 "as if right behind a
+    match" (all earlier positions in the hash chains) produces, from the first position at which it and the real
+    parser both stand right behind a match, exactly the real stream."""
+    x = oracle_mod.lcg_genome(31, 140000)
+    st, pt = _stream(D, x, None, level)
+    for p0 in (32768, 65536, 98304, 70001):
+        ss = D.trace_from(x, p0, level)
+        ln = np.where(ss >> 31, ((ss >> 16) & 0x7fff) + 3, 1).astype(np.int64)
+        ps = p0 + np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.int64)
+        found = None
+        for b in range(len(ss)):
+            if b == 0 or (ss[b - 1] >> 31):
+                a = int(np.searchsorted(pt, ps[b]))
+                if a < len(pt) and pt[a] == ps[b] and a > 0 and (st[a - 1] >> 31):
+                    found = (a, b)
+                    break
+        assert found is not None and ps[found[1]] < p0 + 2048        # well inside the 2 KiB overlap of the segments
+        a, b = found
+        assert np.array_equal(st[a:], ss[b:]) and np.array_equal(pt[a:], ps[b:])
