@@ -38,6 +38,8 @@ def lib():
         L.dfl_oracle_trace_from.restype = u64
         L.dfl_oracle_trace_from.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]
+        L.dfl_oracle_window_trace.restype = ctypes.c_size_t
+        L.dfl_oracle_window_trace.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t]
         L.dfl_oracle_block_bits.restype = u64
         L.dfl_oracle_block_bits.argtypes = [vp, vp]
         _lib = L
@@ -87,6 +89,14 @@ def trace_from(x, start, level=9):
     ns = ctypes.c_size_t(0)
     lib().dfl_oracle_trace_from(a.ctypes.data, a.size, start, level, sym.ctypes.data, sym.size, ctypes.byref(ns))
     return sym[:ns.value]
+
+
+def window_trace(x, level=9):
+    """Per block flush: (stream position of the loop top that closed it, stream position of zlib's window[0])."""
+    a = _arr(x)
+    win = np.zeros(a.size // 16383 + 2, dtype=np.uint64)
+    k = lib().dfl_oracle_window_trace(a.ctypes.data, a.size, level, win.ctypes.data, win.size)
+    return [(int(w) >> 32, int(w) & 0xffffffff) for w in win[:k]]
 
 
 def block_bits(lfreq, dfreq):

@@ -123,6 +123,8 @@ typedef struct {
     /* optional trace of the emitted symbols / blocks (debug aid for the GPU port) */
     uint32_t *sym_trace; size_t sym_cap, sym_n;
     uint64_t *blk_trace; size_t blk_cap, blk_n;
+    uint64_t *win_trace;     /* per block: loop-top stream position << 32 | stream position of window[0] at the flush */
+    uint64_t looptop;
 } dfl_state;
 
 static size_t read_buf(dfl_state *s, uint8_t *dst, size_t size)
@@ -386,6 +388,8 @@ static void flush_block(dfl_state *s, int have_buf, unsigned long stored_len, in
         s->bits += 3 + (uint64_t)s->opt_len;
     }
     if (s->blk_trace && s->blk_n < s->blk_cap) s->blk_trace[s->blk_n] = s->bits - before;
+    if (s->win_trace && s->blk_n < s->blk_cap)
+        s->win_trace[s->blk_n] = (s->looptop << 32) | (uint64_t)(s->in_pos - s->lookahead - s->strstart);
     s->blk_n++;
     init_block(s);
     if (last) s->bits = (s->bits + 7) & ~(uint64_t)7;
@@ -425,6 +429,7 @@ static void deflate_slow(dfl_state *s)
             fill_window(s);
             if (s->lookahead == 0) break;
         }
+        s->looptop = (uint64_t)(s->in_pos - s->lookahead);      /* stream position of strstart at this loop top */
         hash_head = 0;
         if (s->lookahead >= MIN_MATCH) INSERT_STRING(s, s->strstart, hash_head);
         if (s->abs_pos < s->start) {                 /* priming: like a preset dictionary, nothing is parsed or emitted */
@@ -469,6 +474,7 @@ static void deflate_slow(dfl_state *s)
         (void)tally_lit(s, s->window[s->strstart - 1]);
         s->match_available = 0;
     }
+    s->looptop = (uint64_t)s->in_pos;
     FLUSH_BLOCK(s, 1);
 }
 
@@ -533,6 +539,20 @@ uint64_t dfl_oracle_trace_from(const uint8_t *a, size_t na, size_t start, int le
     deflate_slow(s);
     r = s->bits >> 3;
     if (n_sym) *n_sym = s->sym_n;
+    free(s);
+    return r;
+}
+
+/* Per block: (loop-top stream position << 32) | stream position of window[0] when the block was flushed.
+ * Returns the number of blocks. */
+size_t dfl_oracle_window_trace(const uint8_t *a, size_t na, int level, uint64_t *win, size_t cap)
+{
+    size_t r;
+    dfl_state *s = dfl_new(a, na, NULL, 0, level);
+    if (!s) return 0;
+    s->win_trace = win; s->blk_cap = cap;
+    deflate_slow(s);
+    r = s->blk_n;
     free(s);
     return r;
 }

@@ -178,3 +178,27 @@ def test_a_parser_started_mid_stream_joins_the_true_stream(D, oracle_mod, level)
         assert found is not None and ps[found[1]] < p0 + 2048        # well inside the 2 KiB overlap of the segments
         a, b = found
         assert np.array_equal(st[a:], ss[b:]) and np.array_equal(pt[a:], ps[b:])
+
+
+def _window_base(p0, n):
+    """Python statement of dfl_window_base (snacc_amd/csrc/snk_deflate.hip.h): where zlib's window starts when the
+    parser stands at loop top p0 of an n-byte stream."""
+    base = ((p0 - 65275) >> 15) << 15 if p0 >= 65275 else 0
+    while True:
+        t = base + (65274 if n <= base + 65535 else 65275)
+        if p0 < t:
+            return base
+        base += 32768
+
+
+def test_window_slide_positions_closed_form(D, oracle_mod):
+    """The GPU path decides "may this block be stored" from a closed form of zlib's window position; the oracle
+    slides a real window.  Same position at every block flush, for lengths around every kind of edge."""
+    rng = np.random.default_rng(9)
+    lens = [1000, 65274, 65275, 65536, 65537, 65798, 98041, 98042, 98043, 98304, 130809, 130810, 131072, 163840, 200001]
+    lens += [int(v) for v in rng.integers(60000, 400000, 12)]
+    for n in lens:
+        for kind in (0, 1):                      # DNA (long blocks) and random bytes (short stored blocks)
+            a = _gen(rng, kind, n)
+            for p0, base in D.window_trace(a, 9):
+                assert _window_base(p0, n) == base, (n, kind, p0, base)
