@@ -38,6 +38,8 @@ def lib():
         L.dfl_oracle_trace_from.restype = u64
         L.dfl_oracle_trace_from.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]
+        L.dfl_oracle_bytes_behind_end.restype = None
+        L.dfl_oracle_bytes_behind_end.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, vp]
         L.dfl_oracle_window_trace.restype = ctypes.c_size_t
         L.dfl_oracle_window_trace.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t]
         L.dfl_oracle_block_bits.restype = u64
@@ -89,6 +91,14 @@ def trace_from(x, start, level=9):
     ns = ctypes.c_size_t(0)
     lib().dfl_oracle_trace_from(a.ctypes.data, a.size, start, level, sym.ctypes.data, sym.size, ctypes.byref(ns))
     return sym[:ns.value]
+
+
+def bytes_behind_end(x, level=9):
+    """The 258 bytes zlib's window holds right behind the last input byte when the stream is finished."""
+    a = _arr(x)
+    out = np.zeros(258, dtype=np.uint8)
+    lib().dfl_oracle_bytes_behind_end(a.ctypes.data, a.size, level, out.ctypes.data)
+    return out
 
 
 def window_trace(x, level=9):

@@ -543,6 +543,20 @@ uint64_t dfl_oracle_trace_from(const uint8_t *a, size_t na, size_t start, int le
     return r;
 }
 
+/* What zlib's compare loop can read behind the end of the input: the 258 window bytes that follow the last input
+ * byte, as they stand when the stream is finished. */
+void dfl_oracle_bytes_behind_end(const uint8_t *a, size_t na, int level, uint8_t *out /* [258] */)
+{
+    dfl_state *s = dfl_new(a, na, NULL, 0, level);
+    if (!s) return;
+    deflate_slow(s);
+    for (unsigned i = 0; i < MAX_MATCH; i++) {
+        const unsigned idx = s->strstart + s->lookahead + i;
+        out[i] = idx < WINDOW_SIZE ? s->window[idx] : 0;
+    }
+    free(s);
+}
+
 /* Per block: (loop-top stream position << 32) | stream position of window[0] when the block was flushed.
  * Returns the number of blocks. */
 size_t dfl_oracle_window_trace(const uint8_t *a, size_t na, int level, uint64_t *win, size_t cap)

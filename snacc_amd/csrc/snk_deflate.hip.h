@@ -161,15 +161,17 @@ __global__ void dfl_kinv_kernel(const uint32_t *kocc, const uint16_t *skey, cons
 struct DflStream {
     const uint8_t *X, *Y;
     uint32_t lx, ly, n;
+    bool slid;                // zlib's window has slid at least once at the current loop top
 };
 
 // Behind the end of the input zlib's compare loop reads whatever the window buffer still holds:
-// zeros while the window never slid (n <= 64 KiB), else the bytes 32 KiB earlier (the upper half
-// keeps its old content after a slide).
+// zeros while the window has not slid, else the bytes 32 KiB earlier (the buffer keeps its old
+// content after a slide).  The first slide happens at the first loop top >= 65 274 with fewer than
+// 262 bytes left -- also in a stream of 65 275 .. 65 536 bytes that fitted the buffer (s.slid).
 __device__ __forceinline__ uint32_t dfl_byte(const DflStream &s, uint32_t a)
 {
     if (a >= s.n) {
-        if (s.n <= 65536u) return 0u;
+        if (!s.slid) return 0u;
         a -= 32768u;
     }
     return a < s.lx ? s.X[a] : s.Y[a - s.lx];
@@ -811,6 +813,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
     S.X = T.bytes + sx.boff; S.lx = sx.len;
     S.Y = pair ? T.bytes + sy.boff : S.X; S.ly = pair ? sy.len : 0u;
     S.n = S.lx + S.ly;
+    S.slid = S.n > 65536u;                                   // (updated at every loop top, see there)
     const uint32_t lx = S.lx, n = S.n;
     const uint32_t *occx = T.occ + sx.ioff, *bsx = T.bstart + (size_t)job.xi * (DFL_NHASH + 1u);
     const uint32_t *occy = T.occ + sy.ioff;
@@ -881,6 +884,9 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
         if (SEG && w.nsym >= seg_cap) break;
         const uint32_t la = n - p;
         const uint32_t prev_length = match_length, prev_match = match_start;
+        // bytes behind the end can be read from p + 258 > n on; by then a stream longer than the buffer has slid,
+        // a shorter one slides at the first loop top >= 65 274 (65 275 for n = 65 536) -- dfl_window_base's rule
+        S.slid = n > 65536u || p >= (n <= 65535u ? 65274u : 65275u);
         match_length = 2u;
         DFL_T(ta); iters++;
         if (la >= 3u && prev_length < T.lazy) {

@@ -202,3 +202,21 @@ def test_window_slide_positions_closed_form(D, oracle_mod):
             a = _gen(rng, kind, n)
             for p0, base in D.window_trace(a, 9):
                 assert _window_base(p0, n) == base, (n, kind, p0, base)
+
+
+def test_bytes_behind_the_end_of_the_input(D, oracle_mod):
+    """zlib's match compare may run past the last input byte into whatever its window still holds.  The GPU path
+    (dfl_byte in snk_deflate.hip.h) says: zeros while the window has not slid, else the bytes 32 KiB earlier --
+    and the window slides for the first time at the first loop top >= 65 274 that has fewer than 262 bytes left, so a
+    stream of 65 275 .. 65 536 bytes ends with a slid window although it fitted the buffer.  Checked against the
+    oracle's real window as it stands at the end."""
+    rng = np.random.default_rng(17)
+    for n in [5, 300, 40000, 65273, 65274, 65275, 65276, 65535, 65536, 65537, 65600, 98000, 98304, 98305, 131071, 131072,
+              131073, 200001] + [int(v) for v in rng.integers(65537, 500000, 10)]:
+        a = _gen(rng, 1, n)                       # random bytes: any wrong source position shows
+        got = D.bytes_behind_end(a, 9)
+        if _window_base(n, n) == 0:               # the state at the last loop top (p = n): slid for every n >= 65 274
+            exp = np.zeros(258, dtype=np.uint8)
+        else:
+            exp = a[n - 32768:n - 32768 + 258]
+        assert np.array_equal(got[:len(exp)], exp), n

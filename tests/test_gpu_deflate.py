@@ -193,6 +193,34 @@ def test_argument_and_state_errors(hip):
         assert [int(v) for v in ctx.deflate_singles("gzip")] == [len(gzip.compress(b"ACGT" * 100)), len(gzip.compress(b"GATTACA" * 50))]
 
 
+def test_matches_running_into_the_end_of_a_64k_stream(hip, oracle_mod):
+    """Streams of 65 275 .. 65 536 bytes end with zlib's window slid once, so a match compare that runs past the
+    last byte sees the data 32 KiB earlier, not zeros (CPU: test_bytes_behind_the_end_of_the_input).  Inputs whose
+    tail occurs twice before -- the older copy continues like those remnant bytes, the newer one does not --
+    as single sequences and as pairs whose total length falls into that range."""
+    rng = np.random.default_rng(65275)
+    seqs = []
+    for n in (65275, 65300, 65400, 65500, 65536, 65274, 65537):
+        a = rng.choice(ACGT, n)
+        for tl in (12, 40):
+            tail = a[n - tl:].copy()
+            rem = a[n - 32768:n - 32768 + 200].copy()            # what the window holds behind the end after the slide
+            q2, q1 = n - 20000 - tl, n - 5000 - tl
+            b = a.copy()
+            b[q2:q2 + tl] = tail
+            b[q2 + tl:q2 + tl + 200] = rem                        # the older copy goes on like the remnant
+            b[q1:q1 + tl] = tail
+            b[q1 + tl] = ACGT[(int(np.flatnonzero(ACGT == rem[0])[0]) + 1) % 4]   # the newer one does not
+            seqs.append(b)
+    seqs += [seqs[0][:30000], seqs[3][30000:]]                    # 30 000 + 35 500 = 65 500 as a pair
+    _check_all_vs_codec(hip, seqs[:6] + seqs[-2:])
+    raw = [_b(s) for s in seqs]
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        for alg, fn in CODEC.items():
+            assert [int(v) for v in ctx.deflate_singles(alg)] == [len(fn(r)) for r in raw], alg
+
+
 def test_pair_lists_tiles_and_single_items(hip, oracle_mod):
     seqs = [oracle_mod.lcg_genome(60 + i, 66000 + 7777 * i) for i in range(7)]
     with hip.HipContext(0) as ctx:
