@@ -9,6 +9,9 @@ leg may import this package.  The product (``snacc_amd``) never does.
 * ``ncd_oracle.py``  -- Python restatement of ref:snacc/pairwise_ncd.py (sequence
   extraction, ``+33`` getsizeof, NCD formula) and ref:snacc/cli.py:102-142 (pair
   set, matrix layout).
+* ``deflate_oracle.c`` / ``deflate_rules.c`` / ``deflate.py`` -- zlib 1.2.11 deflate sizes behind
+  ``gzip.compress`` / ``zlib.compress`` (ref:snacc/pairwise_ncd.py:73-78): a window-faithful
+  restatement, and the rules the GPU kernel applies, both pinned against the interpreter's zlib.
 * ``liblz4_ref.py``  -- optional ctypes binding to the liblz4 1.9.3 *binary* of the
   image, used to pin the C restatement (differential fuzz).  Test-only.
 """

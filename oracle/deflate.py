@@ -18,8 +18,8 @@ ZLIB_LEVEL, ZLIB_WRAPPER = 6, 6       # zlib.compress: level 6,  2 B header + 4 
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "deflate_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("deflate_oracle.c", "deflate_rules.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_deflate.so"])
     return _SO
 
@@ -38,6 +38,8 @@ def lib():
         L.dfl_oracle_trace_from.restype = u64
         L.dfl_oracle_trace_from.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]
+        L.dfl_rules_raw_size.restype = u64
+        L.dfl_rules_raw_size.argtypes = [vp, ctypes.c_size_t, ctypes.c_int]
         L.dfl_oracle_bytes_behind_end.restype = None
         L.dfl_oracle_bytes_behind_end.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, vp]
         L.dfl_oracle_window_trace.restype = ctypes.c_size_t
@@ -91,6 +93,12 @@ def trace_from(x, start, level=9):
     ns = ctypes.c_size_t(0)
     lib().dfl_oracle_trace_from(a.ctypes.data, a.size, start, level, sym.ctypes.data, sym.size, ctypes.byref(ns))
     return sym[:ns.value]
+
+
+def rules_raw_size(x, level=9):
+    """Raw deflate size by the RULES the GPU kernel applies (oracle/deflate_rules.c), not by zlib's data structures."""
+    a = _arr(x)
+    return int(lib().dfl_rules_raw_size(a.ctypes.data, a.size, level))
 
 
 def bytes_behind_end(x, level=9):

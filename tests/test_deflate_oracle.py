@@ -220,3 +220,26 @@ def test_bytes_behind_the_end_of_the_input(D, oracle_mod):
         else:
             exp = a[n - 32768:n - 32768 + 258]
         assert np.array_equal(got[:len(exp)], exp), n
+
+
+def test_rules_model_of_the_gpu_kernel_matches_the_codec(D, oracle_mod):
+    """oracle/deflate_rules.c states the rules the GPU kernel applies -- data-only hash chains, the distance / budget /
+    nice-length rules of a chain walk, bytes behind the end, the closed-form window position -- without any of zlib's
+    window machinery.  Same sizes as the codec: fuzz sets (all alphabets), window-edge lengths, tails that repeat."""
+    from fuzzgen import make_set
+    rng = np.random.default_rng(5)
+    seqs = [a for seed in range(300, 312) for a in make_set(seed)]
+    seqs += [_gen(rng, k, n) for n in (0, 1, 2, 3, 4, 65273, 65274, 65275, 65276, 65535, 65536, 65537, 98304) for k in (0, 1)]
+    for n in (65275, 65400, 65536, 70000):                       # a tail that occurs twice before (see the GPU test)
+        a = rng.choice(ACGT, n)
+        tail, rem = a[n - 40:].copy(), a[n - 32768:n - 32768 + 200].copy()
+        a[n - 20040:n - 20000] = tail
+        a[n - 20000:n - 19800] = rem
+        a[n - 5040:n - 5000] = tail
+        seqs.append(a)
+    x, y = oracle_mod.lcg_genome(3, 40000), oracle_mod.lcg_genome(4, 25400)
+    seqs.append(np.concatenate([x, y]))                          # a pair is a concatenation
+    for a in seqs:
+        b = bytes(a)
+        assert D.rules_raw_size(a, 9) + 18 == len(gzip.compress(b)), len(a)
+        assert D.rules_raw_size(a, 6) + 6 == len(zlib.compress(b)), len(a)
