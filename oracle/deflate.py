@@ -38,6 +38,8 @@ def lib():
         L.dfl_oracle_trace_from.restype = u64
         L.dfl_oracle_trace_from.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]
+        L.dfl_rules_check_kpass.restype = u64
+        L.dfl_rules_check_kpass.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(u64)]
         L.dfl_rules_raw_size.restype = u64
         L.dfl_rules_raw_size.argtypes = [vp, ctypes.c_size_t, ctypes.c_int]
         L.dfl_oracle_bytes_behind_end.restype = None
@@ -99,6 +101,15 @@ def rules_raw_size(x, level=9):
     """Raw deflate size by the RULES the GPU kernel applies (oracle/deflate_rules.c), not by zlib's data structures."""
     a = _arr(x)
     return int(lib().dfl_rules_raw_size(a.ctypes.data, a.size, level))
+
+
+def rules_check_kpass(x, level=9):
+    """(violations, probes decided by the K-pass): where the six-byte shortcut of the gzip kernel would decide a probe,
+    does it decide like the full chain walk?"""
+    a = _arr(x)
+    nk = ctypes.c_uint64(0)
+    v = lib().dfl_rules_check_kpass(a.ctypes.data, a.size, level, ctypes.byref(nk))
+    return int(v), int(nk.value)
 
 
 def bytes_behind_end(x, level=9):

@@ -40,7 +40,83 @@ static unsigned rules_byte(const rules_stream *s, size_t i)
     return s->a[i];
 }
 
+/* One chain walk by the rules.  Returns 1 if a search took place; *best / *mstart as zlib leaves them. */
+static int rules_walk(const rules_stream *S, const int32_t *prevpos, size_t p, unsigned prev_length, unsigned chain,
+                      unsigned nice, unsigned *best_out, unsigned *mstart)
+{
+    unsigned best = prev_length, j = 0;
+    int searched = 0;
+    int32_t q = prevpos[p];
+    while (q >= 0 && j < chain) {
+        const size_t dist = p - (size_t)q;
+        unsigned len = 0;
+        if (q == 0 || dist > (j == 0 ? 32506u : 32505u)) break;
+        searched = 1;
+        while (len < MAX_MATCH && rules_byte(S, p + len) == rules_byte(S, (size_t)q + len)) len++;
+        if (len > best) {
+            best = len;
+            *mstart = (unsigned)q;
+            if (len >= nice) break;
+        }
+        q = prevpos[q];
+        j++;
+    }
+    *best_out = best;
+    return searched;
+}
+
+static unsigned rules_hash6(const uint8_t *p)
+{
+    uint64_t v = 0;
+    memcpy(&v, p, 6);
+    return (unsigned)((v * 0x9E3779B97F4A7C15ull) >> 48);
+}
+
+/* The K-pass of the gzip kernel: only the chain members that share the probe's 16-bit hash of six bytes (and its
+ * 3-byte hash), each with its position j3 in the full chain.  Returns 1 if the kernel would take the result
+ * ("a match of >= 6 bytes that beats prev_length"), 2 if it would skip the search because prev_length >= 5. */
+static int rules_kpass(const rules_stream *S, const int32_t *prevpos, size_t p, unsigned prev_length, unsigned chain,
+                       unsigned nice, unsigned *best_out, unsigned *mstart)
+{
+    const unsigned h6 = rules_hash6(S->a + p);
+    unsigned best = prev_length, j3 = 0, ms = *mstart;
+    int32_t q = prevpos[p];
+    for (; q >= 0; q = prevpos[q], j3++) {
+        const size_t dist = p - (size_t)q;
+        unsigned len = 0;
+        if (dist > (j3 == 0 ? 32506u : 32505u)) break;          /* the lists are in falling position order */
+        if ((size_t)q + 6 > S->n || rules_hash6(S->a + q) != h6) continue;   /* not in the six-byte bucket */
+        if (q == 0 || j3 >= chain) continue;
+        while (len < MAX_MATCH && rules_byte(S, p + len) == rules_byte(S, (size_t)q + len)) len++;
+        if (len > best) {
+            best = len;
+            ms = (unsigned)q;
+            if (len >= nice) break;
+        }
+    }
+    if (best >= 6 && best > prev_length) { *best_out = best; *mstart = ms; return 1; }
+    return prev_length >= 5 ? 2 : 0;
+}
+
+/* Runs the parse by the rules and counts the probes at which the K-pass would have decided differently from the full
+ * chain walk (0 = the argument of DESIGN.md section 10 holds on this input).  *n_k = probes the K-pass decided. */
+uint64_t dfl_rules_check_kpass(const uint8_t *a, size_t n, int level, uint64_t *n_k);
+
+uint64_t dfl_rules_raw_size_impl(const uint8_t *a, size_t n, int level, uint64_t *violations, uint64_t *n_k);
+
 uint64_t dfl_rules_raw_size(const uint8_t *a, size_t n, int level)
+{
+    return dfl_rules_raw_size_impl(a, n, level, NULL, NULL);
+}
+
+uint64_t dfl_rules_check_kpass(const uint8_t *a, size_t n, int level, uint64_t *n_k)
+{
+    uint64_t v = 0;
+    (void)dfl_rules_raw_size_impl(a, n, level, &v, n_k);
+    return v;
+}
+
+uint64_t dfl_rules_raw_size_impl(const uint8_t *a, size_t n, int level, uint64_t *violations, uint64_t *n_k)
 {
     dfl_state *s = dfl_new(a, n, NULL, 0, level);
     int32_t *prevpos, *last;
@@ -69,24 +145,21 @@ uint64_t dfl_rules_raw_size(const uint8_t *a, size_t n, int level)
         S.slid = n > 65536 || p >= (n <= 65535 ? 65274u : 65275u);
         match_length = 2;
         if (la >= 3 && prev_length < s->cfg.max_lazy) {
-            unsigned chain = s->cfg.max_chain, nice = s->cfg.nice_length, best = prev_length, j = 0;
-            int searched = 0;
-            int32_t q = prevpos[p];
+            unsigned chain = s->cfg.max_chain, nice = s->cfg.nice_length, best = prev_length;
+            int searched;
+            const unsigned ms_in = match_start;
             if (prev_length >= s->cfg.good_length) chain >>= 2;
             if (nice > la) nice = (unsigned)la;
-            while (q >= 0 && j < chain) {
-                const size_t dist = p - (size_t)q;
-                unsigned len = 0;
-                if (q == 0 || dist > (j == 0 ? 32506u : 32505u)) break;
-                searched = 1;
-                while (len < MAX_MATCH && rules_byte(&S, p + len) == rules_byte(&S, (size_t)q + len)) len++;
-                if (len > best) {
-                    best = len;
-                    match_start = (unsigned)q;
-                    if (len >= nice) break;
+            searched = rules_walk(&S, prevpos, p, prev_length, chain, nice, &best, &match_start);
+            if (violations && la >= MIN_LOOKAHEAD) {              /* where the kernel's K-pass applies */
+                unsigned kbest = prev_length, kms = ms_in;
+                const int k = rules_kpass(&S, prevpos, p, prev_length, chain, nice, &kbest, &kms);
+                if (k == 1) { if (n_k) (*n_k)++; if (!searched || kbest != best || kms != match_start) (*violations)++; }
+                else if (k == 2) {                                /* the emission must not depend on this search */
+                    const unsigned ml = searched ? (best <= la ? best : (unsigned)la) : 2u;
+                    if (n_k) (*n_k)++;
+                    if (ml > prev_length) (*violations)++;
                 }
-                q = prevpos[q];
-                j++;
             }
             if (searched) {
                 match_length = best <= la ? best : (unsigned)la;

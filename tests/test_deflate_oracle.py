@@ -243,3 +243,20 @@ def test_rules_model_of_the_gpu_kernel_matches_the_codec(D, oracle_mod):
         b = bytes(a)
         assert D.rules_raw_size(a, 9) + 18 == len(gzip.compress(b)), len(a)
         assert D.rules_raw_size(a, 6) + 6 == len(zlib.compress(b)), len(a)
+
+
+def test_six_byte_shortcut_decides_like_the_full_chain_walk(D, oracle_mod):
+    """The gzip kernel first looks only at the chain members that share the probe's hash of six bytes and takes their
+    result if it is a match of >= 6 bytes.  The rules program replays every probe both ways."""
+    from fuzzgen import make_set
+    rng = np.random.default_rng(6)
+    seqs = [a for seed in range(500, 508) for a in make_set(seed)]
+    seqs += [oracle_mod.lcg_genome(9, 300000), rng.choice(np.frombuffer(b"AC", dtype=np.uint8), 120000),
+             np.repeat(rng.choice(ACGT, 3000), 40)[:100000].copy(), np.tile(oracle_mod.lcg_genome(8, 700), 200)]
+    decided = 0
+    for a in seqs:
+        for level in (9, 6):
+            v, k = D.rules_check_kpass(a, level)
+            assert v == 0, (len(a), level, v)
+            decided += k
+    assert decided > 300000
