@@ -50,3 +50,23 @@ def test_stats_match_survey_workload(oracle_mod):
     assert 180000 < st["sequences"] < 185000
     assert st["too_far"] == 0 and st["bailouts"] == 0
     assert 0.20 < (st["search_probes"] + st["chain_probes"]) / 1e6 < 0.22
+
+
+def test_u16_bitmap_table_scheme_of_the_2bit_kernel(oracle_mod):
+    """The 2-bit kernel keeps, per hash slot, a 16-bit offset inside the current block plus a "written in this block"
+    bit, and ages the table at block transitions (tests/lz4_table_model.py).  Run through a plain Python LZ4-frame
+    parse, that scheme and liblz4's absolute-position table give the oracle's sizes -- on random genomes, tandem
+    repeats with mutations (blocks that end in matches) and a low-complexity run, three blocks and more each."""
+    import numpy as np
+    from lz4_table_model import U16BitmapTable, PlainTable, frame_size
+    rng = np.random.default_rng(2510)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rep = np.tile(rng.choice(acgt, 900), 160)[:140000].copy()
+    hit = rng.random(len(rep)) < 0.02
+    rep[hit] = rng.choice(acgt, int(hit.sum()))
+    seqs = [oracle_mod.lcg_genome(3, 140001), rep, np.repeat(rng.choice(acgt, 5000), 30)[:135000].copy(),
+            np.concatenate([oracle_mod.lcg_genome(4, 70000), oracle_mod.lcg_genome(5, 66000)])]
+    for a in seqs:
+        exp = oracle_mod.lz4f_size(a)
+        assert frame_size(a, PlainTable()) == exp
+        assert frame_size(a, U16BitmapTable()) == exp
