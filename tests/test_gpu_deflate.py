@@ -197,7 +197,9 @@ def test_matches_running_into_the_end_of_a_64k_stream(hip, oracle_mod):
     """Streams of 65 275 .. 65 536 bytes end with zlib's window slid once, so a match compare that runs past the
     last byte sees the data 32 KiB earlier, not zeros (CPU: test_bytes_behind_the_end_of_the_input).  Inputs whose
     tail occurs twice before -- the older copy continues like those remnant bytes, the newer one does not --
-    as single sequences and as pairs whose total length falls into that range."""
+    as single sequences and as pairs whose total length falls into that range.  (zlib clamps nice_match to the
+    bytes left, so the first chain member that reaches the end wins either way: this guards the lengths and the
+    end-of-stream handling around that range rather than the remnant rule itself.)"""
     rng = np.random.default_rng(65275)
     seqs = []
     for n in (65275, 65300, 65400, 65500, 65536, 65274, 65537):
