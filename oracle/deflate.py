@@ -38,6 +38,8 @@ def lib():
         L.dfl_oracle_trace_from.restype = u64
         L.dfl_oracle_trace_from.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]
+        L.dfl_rules_pair_size.restype = u64
+        L.dfl_rules_pair_size.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_int]
         L.dfl_rules_check_kpass.restype = u64
         L.dfl_rules_check_kpass.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(u64)]
         L.dfl_rules_raw_size.restype = u64
@@ -101,6 +103,13 @@ def rules_raw_size(x, level=9):
     """Raw deflate size by the RULES the GPU kernel applies (oracle/deflate_rules.c), not by zlib's data structures."""
     a = _arr(x)
     return int(lib().dfl_rules_raw_size(a.ctypes.data, a.size, level))
+
+
+def rules_pair_size(x, y, level=9):
+    """Raw deflate size of x+y by the PAIR job of the GPU path as a CPU program: restart from x's own stream, seam parse
+    over per-sequence chains plus the seam positions, resynchronisation with y's own stream, pricing of the splice."""
+    a, b = _arr(x), _arr(y)
+    return int(lib().dfl_rules_pair_size(a.ctypes.data, a.size, b.ctypes.data, b.size, level))
 
 
 def rules_check_kpass(x, level=9):

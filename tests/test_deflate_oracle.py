@@ -260,3 +260,20 @@ def test_six_byte_shortcut_decides_like_the_full_chain_walk(D, oracle_mod):
             assert v == 0, (len(a), level, v)
             decided += k
     assert decided > 300000
+
+
+def test_pair_job_of_the_gpu_path_as_a_cpu_program(D, oracle_mod):
+    """oracle/deflate_rules.c, dfl_rules_pair_size: the pair job exactly as the kernel does it -- chains per sequence
+    plus the two seam positions, restart from x's own stream, resynchronisation with y's own stream, pricing of the
+    spliced symbol stream -- against the codec on all ordered pairs of fuzz sets and on short / empty / edge inputs."""
+    from fuzzgen import make_set
+    sets = [make_set(602), make_set(20016)]
+    sets.append([np.zeros(0, np.uint8), np.frombuffer(b"A", dtype=np.uint8), np.frombuffer(b"ACGTAC", dtype=np.uint8),
+                 oracle_mod.lcg_genome(1, 599), oracle_mod.lcg_genome(2, 601), oracle_mod.lcg_genome(3, 33000),
+                 oracle_mod.lcg_genome(4, 65536), oracle_mod.lcg_genome(5, 70000)])
+    for seqs in sets:
+        raw = [bytes(s) for s in seqs]
+        for i, a in enumerate(seqs):
+            for j, b in enumerate(seqs):
+                assert D.rules_pair_size(a, b, 9) + 18 == len(gzip.compress(raw[i] + raw[j])), (len(a), len(b))
+                assert D.rules_pair_size(a, b, 6) + 6 == len(zlib.compress(raw[i] + raw[j])), (len(a), len(b))
