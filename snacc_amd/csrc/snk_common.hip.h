@@ -25,7 +25,17 @@
 //                     an independent second implementation for cross-checks.
 //   snk_ingest.hip.h  classify / 2-bit pack / hash sets / snapshot conversion.
 #pragma once
+#ifdef SNK_HOST_EMU                 // g++ build of one lane for the CPU tests (tests/emu/); never shipped
+#include "snk_host_emu.h"
+#define SNK_AS1
+#define SNK_AS3
+#define SNK_COOP(stride) 1u         // the one emulated lane walks cooperative loops alone
+#else
 #include <hip/hip_runtime.h>
+#define SNK_AS1 __attribute__((address_space(1)))
+#define SNK_AS3 __attribute__((address_space(3)))
+#define SNK_COOP(stride) (stride)
+#endif
 #include <stdint.h>
 
 #define SNK_BLOCK       65536u
@@ -74,16 +84,16 @@ __device__ __forceinline__ uint32_t snk_lit_ext(uint32_t lit)
 }
 
 // global-memory (address space 1) pointers keep hipcc on global_load_* instead of flat_load_*
-typedef __attribute__((address_space(1))) const uint8_t snk_g8;
+typedef SNK_AS1 const uint8_t snk_g8;
 struct __attribute__((packed)) SnkU64 { uint64_t v; };
 struct __attribute__((packed)) SnkU32 { uint32_t v; };
 __device__ __forceinline__ uint64_t snk_ld8g(snk_g8 *p)
 {
-    return ((__attribute__((address_space(1))) const SnkU64 *)p)->v;   // byte-aligned 8-byte load
+    return ((SNK_AS1 const SnkU64 *)p)->v;   // byte-aligned 8-byte load
 }
 __device__ __forceinline__ uint32_t snk_ld4g(snk_g8 *p)
 {
-    return ((__attribute__((address_space(1))) const SnkU32 *)p)->v;   // byte-aligned 4-byte load
+    return ((SNK_AS1 const SnkU32 *)p)->v;   // byte-aligned 4-byte load
 }
 
 // Diagnostic trace (only with -DSNK_TRACE, `make trace`; never shipped): lane 0 of workgroup 0

@@ -344,7 +344,11 @@ __device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T,
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     unsigned long long acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, iters = 0;
 #endif
-    const __attribute__((address_space(3))) uint16_t *const lut0 = (const __attribute__((address_space(3))) uint16_t *)0;
+#ifdef SNK_HOST_EMU
+    const uint16_t *const lut0 = slot;
+#else
+    const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
+#endif
 
     for (;;) {
         // ======== head: serve rare pre-conditions, then start the LUT reads ========
@@ -518,13 +522,15 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
 __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
                                                      uint32_t lanes, uint32_t *out, uint32_t *status)
 {
+#ifndef SNK_HOST_EMU
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+#endif
     uint16_t *slot = (uint16_t *)snk_lds8;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
     const uint32_t chains = lanes * waves;
 
-    for (uint32_t t = tid; t < 512u; t += blockDim.x)
+    for (uint32_t t = tid; t < 512u; t += SNK_COOP(blockDim.x))
         ((uint32_t *)slot)[t] = ((const uint32_t *)T.lut_slot)[t];
 
     // chain c of the workgroup -> lane c / waves of wave c % waves  (spreads a
@@ -547,7 +553,7 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         const uint32_t spos = T.snap_pos[xi];
         const bool use = (snp == 0) && (spos != 0u);
         const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
-        for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += 64u) {
+        for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
             uint32_t v = 0u;
             if (use) {
                 const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
@@ -558,7 +564,7 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
             ((uint32_t *)dst)[t] = v;
         }
         // no snapshot: stream start, every slot holds position 0 "written in this block"
-        if (lane < SNK_FBMWORDS) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[lane] = use ? 0u : 0xFFFFFFFFu;
+        for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;
     }
     __syncthreads();
 

@@ -1,0 +1,80 @@
+// fast_emu.cpp -- TEST INFRASTRUCTURE.  Runs the 2-bit kernel's source (snk_fast.hip.h) on the CPU,
+// one lane at a time (snk_host_emu.h), over the same HBM layout snk_upload builds: packed arena,
+// 5-mer -> slot LUT, prefix snapshots from the singles pass, then the ordered pairs.
+// Build: g++ -O1 -DSNK_HOST_EMU -I tests/emu -I snacc_amd/csrc -shared -fPIC -o tests/emu/libfast_emu.so tests/emu/fast_emu.cpp
+#include "snk_fast.hip.h"
+#include <vector>
+
+namespace {
+
+uint32_t host_hash5(const uint8_t *p)
+{
+    uint64_t v = 0;
+    memcpy(&v, p, 5);
+    return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
+}
+
+} // namespace
+
+extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t *lens,
+                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes)
+{
+    const char code2byte[4] = { 'A', 'C', 'T', 'G' };
+    std::vector<uint16_t> slot(1024, 0);
+    {
+        std::vector<int> slot_of_hash(4096, -1);
+        int n_slots = 0;
+        for (uint32_t k = 0; k < 1024; ++k) {
+            uint8_t b[5];
+            for (int i = 0; i < 5; ++i) b[i] = (uint8_t)code2byte[(k >> (2 * i)) & 3];
+            const uint32_t h = host_hash5(b);
+            if (slot_of_hash[h] < 0) slot_of_hash[h] = n_slots++;
+            slot[k] = (uint16_t)slot_of_hash[h];
+        }
+        if (n_slots > (int)SNK_FSLOTS) return -1;
+    }
+    std::vector<uint8_t> ok((size_t)n, 0);
+    std::vector<uint32_t> poff((size_t)n, 0), len((size_t)n), spos((size_t)n);
+    size_t ptot = 4 * SNK_PAD;
+    for (int g = 0; g < n; ++g) {
+        len[g] = (uint32_t)lens[g];
+        bool pure = lens[g] > 0;
+        for (uint64_t i = 0; i < lens[g]; ++i) {
+            const uint8_t c = seqs[g][i];
+            pure &= (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        }
+        ok[g] = pure;
+        if (pure) { poff[g] = (uint32_t)ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; }
+        spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
+    }
+    ptot += 65536;                                   // slack behind the last sequence
+    std::vector<uint8_t> arena(ptot, 0);
+    for (int g = 0; g < n; ++g) {
+        if (!ok[g]) continue;
+        for (uint64_t i = 0; i < lens[g]; ++i)
+            arena[poff[g] + (i >> 2)] |= (uint8_t)(((seqs[g][i] >> 1) & 3u) << (2u * (i & 3u)));
+    }
+    std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), status(1, 0);
+
+    SnkTables T;
+    memset(&T, 0, sizeof T);
+    T.packed_arena = arena.data(); T.packed_off = poff.data(); T.len = len.data();
+    T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data();
+    T.lut_slot = slot.data(); T.header_bytes = header_bytes;
+
+    blockDim.x = 64; threadIdx.x = 0; blockIdx.x = 0;
+    for (int g = 0; g < n; ++g) {
+        singles[g] = 0;
+        if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
+        SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
+        snk_fast_kernel_body(T, &jb, 1u, 1u, singles, status.data());
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            pairs[(size_t)i * n + j] = 0;
+            if (!ok[i] || !ok[j] || lens[i] + lens[j] <= SNK_BLOCK) continue;
+            SnkJob jb; jb.xi = i; jb.yi = j; jb.out_idx = (uint32_t)((size_t)i * n + j); jb.snap = 0;
+            snk_fast_kernel_body(T, &jb, 1u, 1u, pairs, status.data());
+        }
+    return (int)status[0];
+}
