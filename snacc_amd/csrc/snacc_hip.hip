@@ -473,7 +473,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
 
     const size_t n = (size_t)n_seq;
     std::vector<size_t> boff(n), poff(n);
-    size_t btot = SNK_PAD, ptot = 4 * SNK_PAD;      // the packed arena starts with a zero region (empty suffix)
+    size_t btot = SNK_PAD, ptot = SNK_ARENA_SLACK;  // the packed arena starts with a zero region (empty suffix + slack)
     for (size_t g = 0; g < n; ++g) {
         if (lens[g] >= 0x7E000000ull) return fail(c, SNK_E_TOOBIG, "sequence %zu too long (%llu B)", g, (unsigned long long)lens[g]);
         if (lens[g] && !seqs[g]) return fail(c, SNK_E_ARG, "sequence %zu is NULL", g);
@@ -514,6 +514,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         c->is_packed[g] = (flags[g] & 1u) && lens[g] > 0;
         if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
     }
+    ptot += SNK_ARENA_SLACK;
     if (ptot >= 0xFFF00000ull)
         return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the 4 GiB offset range", ptot);
     HIPCHK(c, hipMalloc((void **)&c->d_packed, ptot));

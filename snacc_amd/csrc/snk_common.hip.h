@@ -41,6 +41,11 @@
 #define SNK_BLOCK       65536u
 #define SNK_MAXDIST     65535u
 #define SNK_PAD         64        // zero bytes before and after every sequence buffer
+// Zero bytes before the first and after the last sequence of the 2-bit arena: the steady loop of the
+// 2-bit kernel forms candidate addresses from table entries before it knows they are in range
+// (up to 65 540 bases = 16 385 bytes either side of a sequence), and every such load must stay inside
+// the allocation.  Single-sequence jobs use offset SNK_PAD of this zero region as their empty suffix.
+#define SNK_ARENA_SLACK 16512
 
 // status bits written by kernels
 #define SNK_ST_ITERCAP  1u

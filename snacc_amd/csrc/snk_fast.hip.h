@@ -88,10 +88,11 @@ struct SnkFastLane {
     bool first, in_block;
     // parse state inside the current block
     uint32_t cur, step, nb, anchor, op;
-    uint32_t mfl1, mlimit, olimit, base;   // base = stream position of the block start
+    uint32_t mfl1, mlimit, olimit;
+    uint32_t base;                         // virtual base of the block: its start minus k3; the table stores cur - base
+    uint32_t k3;                           // -lx mod 4: makes (base - lx - 4) a multiple of 4 (see snk_fast_steady)
     uint32_t endcode;                      // 0 running, 1 ends with last-literals, 2 liblz4 gave up (raw)
     bool pending;                          // put(cur-2) owed before the next probe
-    bool yflag;                            // whole block lies > 64 KiB + 8 past the seam, window on y
     SnkWin w;
 };
 
@@ -118,7 +119,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             // prefix snapshot: absolute positions; entries older than one block -> 0 (too far for good)
             uint32_t *dst = T.snap_fast + (size_t)L.xi * SNK_FSLOTS;
             for (uint32_t t = 0; t < SNK_FSLOTS; ++t)
-                dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.pos - 65536u + tbl[t]) : 0u;
+                dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.base + tbl[t]) : 0u;
             T.snap_out[L.xi] = L.total;
         }
         if (L.pos >= L.n) { out[L.out_idx] = L.total + 4u; return true; }      // + end mark
@@ -143,18 +144,16 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             }
         }
         L.first = false;
-        L.base = L.pos;
+        L.base = L.pos - L.k3;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         {
             const uint32_t w0 = snk_fetch32(L.s, L.pos);
             const uint32_t s0 = slot[(w0 >> 8) & 1023u];
-            tbl[s0] = 0;                                              // offset 0 of this block
+            tbl[s0] = (uint16_t)L.k3;                                 // the block start, relative to the virtual base
             atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
         }
         L.cur = L.pos + 1u; L.step = 1u; L.nb = 64u; L.anchor = L.pos; L.op = 0u;
         L.pending = false; L.in_block = true;
-        if (L.cur >= L.s.lx + 4u) snk_win_init(L.w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, L.cur);
-        L.yflag = L.pos >= L.s.lx + SNK_BLOCK + 8u;
         return false;
     }
 }
@@ -194,52 +193,40 @@ __device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur
     if (e2 >= L.mfl1) { L.endcode = 1u; L.mfl1 = 0u; }
 }
 
-// One iteration of the flat parse loop = one probe (search probes and post-match probes are the
-// same code).  Returns true when the lane's frame is complete.
-// YONLY: wave-uniform promise that every lane is in a block lying > 64 KiB + 8 past its seam with
-// its reservoir on y, so cursor and candidate windows both come from y.
-// The common path is branch-free (selects); everything rare funnels into two branches.
-template <bool YONLY>
+// Finish the probe at `cur` whose table operations are already done and whose candidate is `cand`
+// (valid or not): general window fetches (any source, seam included), liblz4's exact match
+// accounting.  This is where the steady loop hands over whenever a lane needs service.
+__device__ __forceinline__ void snk_fast_finish(SnkFastLane &L, uint32_t cur, uint32_t cand, bool valid)
+{
+    const uint32_t wc = snk_fetch32(L.s, cur);
+    const uint32_t wd = snk_fetch32(L.s, valid ? cand : cur);
+    const uint32_t x = wc ^ wd;
+    const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;          // equal bases from cur, 0..12
+    SNK_TRACE_REC(6u, cur, cand, (f << 24) | (valid ? 0x400000u : 0u), cur);
+    if (valid & (f >= 4u)) {
+        snk_fast_match_slow(L, cur, cand, f, L.anchor, L.op);
+    } else {
+        const uint32_t s3 = L.nb >> 6;
+        L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
+    }
+}
+
+// One probe the general way (any source, any state): opens and closes blocks, walks the seam and
+// the stream start, serves lanes the steady loop has handed over.  Returns true when the lane's
+// frame is complete.  Rare path: block edges, seams, service -- speed is irrelevant here.
 __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                               const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur;
-    const uint32_t next = cur + L.step;
-    SnkWin &w = L.w;
-
-    // Block end, bail-out, or not started yet.  This return must come BEFORE the slide below: a
-    // slide consumes w.nx, and only the refill further down restores the "nx = [rb+32, rb+48)"
-    // invariant the next slide relies on.
-    if (__builtin_expect(next > L.mfl1, 0))
+    if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
         return snk_fast_block_step(L, T, tbl, bm, slot, out, status);
-
-    // ---- cursor reservoir: slide by 16 bases when needed, refill always in flight ----
-    uint32_t o = cur - 4u - w.rb;                            // need 0 <= o <= 15
-    {
-        const bool sl = (o - 16u) < 16u;
-        w.r0 = sl ? w.r1 : w.r0;
-        w.r1 = sl ? w.nx : w.r1;
-        w.rb += sl ? 16u : 0u;
-        o -= sl ? 16u : 0u;
-    }
-    bool wslow = false;
-    if (__builtin_expect((o > 15u) | (!YONLY && cur > w.lim), 0)) {
-        // long jump / source change / seam: re-seat the reservoir
-        if (cur >= L.s.lx + 4u)                          snk_win_init(w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
-        else if (cur >= 4u && cur + 12u <= L.s.lx)       snk_win_init(w, L.s.arena, L.s.xoff, 0u, L.s.lx - 12u, cur);
-        else                                             { w.lim = 0u; wslow = true; }
-        o = cur - 4u - w.rb;
-    }
-    SNK_TRACE_REC(8u, w.r0, w.r1, w.nx, cur);
-    const uint32_t wc = (!YONLY && wslow) ? snk_fetch32(L.s, cur) : __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
-
-    // ---- table probe: two LDS round trips (slot LUT, then table + bitmap) ----
+    const uint32_t wc = snk_fetch32(L.s, cur);
     const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
     uint32_t s2 = slot[(wc >> 4) & 1023u];                   // slot of the 5-mer at cur-2
     s2 = L.pending ? s2 : (SNK_FSLOTS - 1u);                 // nothing owed: aim the put at the unused slot
     const uint32_t e = tbl[s1];
     const uint32_t bw = bm[s1 >> 5];
-    const uint32_t c = cur - L.base;                         // offset in the block, 1..65535
+    const uint32_t c = cur - L.base;                         // offset from the virtual base
     const uint32_t bit1 = 1u << (s1 & 31u);
     const bool iscur = (bw & bit1) != 0u;
     uint32_t cand = L.base + e - (iscur ? 0u : 65536u);
@@ -252,235 +239,136 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
     tbl[s1] = (uint16_t)c;
     atomicOr(&bm[s1 >> 5], bit1);
-    const uint32_t s3 = L.nb >> 6;
-    const uint32_t nstep = s3 ? s3 : 1u;
-    cand = valid ? cand : cur;                               // keep the fetch in bounds
-
-    // ---- candidate window: the one global-memory round trip of the probe ----
-    // The reservoir refill is issued right next to it (same address again when nothing slid), so
-    // both loads are in flight together and neither is waited for alone.
-    __builtin_amdgcn_sched_barrier(0);
-    snk_g8 *nxp = L.s.arena + (size_t)(w.soff + ((w.rb + 32u - w.org) >> 2));
-    const uint32_t wd = YONLY ? snk_w32_at(L.s.arena, L.s.yoff, (int32_t)(cand - 4u - L.s.lx))
-                              : snk_fetch32(L.s, cand);
-    w.nx = snk_ld4g(nxp);
-    __builtin_amdgcn_sched_barrier(0);
-    const uint32_t x = wc ^ wd;
-    const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;      // equal bases from cur, 0..12
-    const bool m = valid & (f >= 4u);
-
-    // ---- match bookkeeping, computed for every lane and committed by select ----
-    uint32_t lit = cur - L.anchor;
-    const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;   // equal bases before cur, 0..4
-    uint32_t b = eq < lit ? eq : lit;
-    b = b < cand ? b : cand;
-    lit -= b;
-    uint32_t e2 = cur + f;
-    e2 = e2 < L.mlimit ? e2 : L.mlimit;
-    const uint32_t mc = e2 - (cur - b) - 4u;
-    const uint32_t opn = L.op + lit + 3u;                    // token + literals + offset when no extension bytes
-    const uint32_t big = lit > mc ? lit : mc;
-    // both limitedOutput checks of liblz4 reduce to op + lit + 9 > olimit when lit, mc < 15
-    const bool rare = m & ((b == 4u) | (f == 12u) | (big >= 15u) | (opn + 6u > L.olimit) | (e2 >= L.mfl1));
-    SNK_TRACE_REC(4u, cur, cand, (f << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), cur);
-    if (__builtin_expect(rare, 0)) {
-        snk_fast_match_slow(L, cur, cand, f, L.anchor, L.op);
-        return false;
-    }
-    L.op = m ? opn : L.op;
-    L.anchor = m ? e2 : L.anchor;
-    L.cur = m ? e2 : next;
-    L.step = m ? 1u : nstep;
-    L.nb = m ? 63u : L.nb + 1u;
-    L.pending = m;
+    snk_fast_finish(L, cur, cand, valid);
     return false;
 }
 
-// Candidate window for the seam-aware tight loop, branch-free: one window from x and one from y
-// are always in flight together and combined by selects (a straddling window is x's zero-padded
-// tail OR-ed with y's head shifted into place).
-__device__ __forceinline__ uint32_t snk_fetch32_nobranch(const SnkFastSrc &s, uint32_t p)
+// v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0.
+__device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)__builtin_ctz(v) : 0xFFFFFFFFu; }
+
+// A lane may run the steady loop when its next probe is an ordinary one: inside an open block
+// that has not bailed out, search step 1, literal run and output budget far from their rare
+// ranges, cursor served by the reservoir's source.
+#define SNK_FAST_MAXLIT   15u      // the steady loop leaves at literal runs >= 15 (length-extension bytes)
+#define SNK_FAST_ZONE     80u      // ... and when op comes within 80 bytes of the block's output budget
+__device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 {
-    const int32_t q0 = (int32_t)p - 4;
-    const bool inx = (p + 12u <= s.lx);
-    const bool iny = (q0 >= (int32_t)s.lx);
-    const uint32_t xv = snk_w32_at(s.arena, s.xoff, iny ? 0 : q0);
-    const uint32_t yv = snk_w32_at(s.arena, s.yoff, iny ? q0 - (int32_t)s.lx : 0);
-    const uint32_t sh = 2u * (uint32_t)((int32_t)s.lx - q0);        // 2..30 when straddling
-    const uint32_t mix = xv | (yv << (sh & 31u));
-    return iny ? yv : (inx ? xv : mix);
+    const uint32_t o = L.cur - 4u - L.w.rb;
+    return (L.cur + L.step <= L.mfl1) & (L.step == 1u) & (L.nb < 63u + SNK_FAST_MAXLIT) &
+           (L.op + SNK_FAST_ZONE <= L.olimit) & (o < 32u) & (L.cur <= L.w.lim);
 }
 
-#ifdef SNK_STAMP
-__device__ unsigned long long snk_stamp_buf[8];     // diagnostic build only; read by snk_debug_read_stamps
-#define SNK_STAMP_T(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SNK_STAMP_T(v) do { } while (0)
-#endif
-#define SNK_LOOP_DONE   0
-#define SNK_LOOP_SWITCH 1
-
-// The parse as a tight loop.  The body has no divergent branch: rare events are detected per lane
-// and the wave takes a UNIFORM side exit (__any) to serve them.  The loop is rotated: the slot-LUT
-// reads of the NEXT probe are issued as soon as the match length is known, and this probe's
-// bookkeeping runs in their shadow.
-//   YONLY = true : every active lane's block lies > 64 KiB + 8 past its seam and its reservoir is
-//                  on y (98 % of the probes of a 1 Mbp pair); lanes leave only by finishing.
-//   YONLY = false: seam-aware candidate fetch; lanes whose reservoir cannot serve the cursor (seam,
-//                  stream start) are stepped by the general one-probe routine in the side exit.
-//                  Returns SNK_LOOP_SWITCH (wave-uniform) once every active lane has yflag.
-// Invariant at the head: w.nx holds the bases [rb+32, rb+48).
-template <bool YONLY>
-__device__ __forceinline__ int snk_fast_loop(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
-                                             const uint16_t *slot, uint32_t *out, uint32_t *status)
+// The steady loop: one probe per trip for every lane of the wave, no divergent branch, ONE
+// wave-uniform exit (ballot) taken when any lane needs service; the lanes are then all handed to
+// snk_fast_finish with the state "table operations of the probe done, match not evaluated".
+//
+// Coordinates.  Everything is relative to the block's virtual base vb = L.base (block start minus
+// k3, k3 = -lx mod 4): c = cur - vb is what the table stores; a candidate is t = e + 65536*hit,
+// the offset from vb - 65536 (hit = "written in this block").  k3 makes (vb - lx - 4) a multiple
+// of 4, so a candidate window inside y starts at arena byte yoffB + (t >> 2), bit 2*(t & 3), with
+// no per-probe phase arithmetic; inside x the phase kx is added.  Windows straddling the x/y
+// seam (15 values of t) leave through the exit.  All loads stay inside the arena for ANY t
+// (16 KiB of slack before the first and after the last sequence), so validity is applied to the
+// compare result, not to the address.
+//
+// Order of the table operations: liblz4 does put(cur-2), get(cur), put(cur).  Here the read of
+// slot(cur) is issued first (it heads the dependent chain) and the case slot(cur-2) == slot(cur)
+// is patched in by one select; the bitmap word comes back from the OR that sets the bit of cur
+// (ds_or_rtn_b32).
+__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, uint32_t *bm, const uint16_t *slot)
 {
     SnkWin &w = L.w;
     snk_g8 *const arena = L.s.arena;
-    const uint32_t ybias = L.s.lx + 4u;          // candidate window of stream position p starts at y base p - ybias
-    // The slot LUT sits at LDS address 0 (the kernel has no static LDS; the host checks it):
-    // indexing it from a constant base saves the per-read base addition.
-    (void)slot;
-#ifdef SNK_STAMP
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    unsigned long long acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, iters = 0;
-#endif
 #ifdef SNK_HOST_EMU
     const uint16_t *const lut0 = slot;
 #else
+    (void)slot;                                   // the LUT sits at LDS address 0 (host checks: no static LDS)
     const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
 #endif
+    const uint32_t vb = L.base;
+    const int32_t T0 = (int32_t)(vb - 65536u);                    // stream position of t = 0
+    const int32_t X0 = T0 - 4, Y0 = T0 - 4 - (int32_t)L.s.lx;    // source index of the window of t = 0
+    const uint32_t kx = (uint32_t)X0 & 3u;                        // (Y0 & 3) == 0 by the choice of k3
+    const uint32_t xoffB = L.s.xoff + (uint32_t)(X0 >> 2), yoffB = L.s.yoff + (uint32_t)(Y0 >> 2);
+    const int32_t sx = (int32_t)L.s.lx - 11 - T0;                 // t < sx: window inside x; t >= sx + 15: inside y
+    const uint32_t limw = w.lim == 0xFFFFFFFFu ? w.lim : w.lim + 1u;
+    const uint32_t limc = (L.mfl1 < limw ? L.mfl1 : limw) - vb;   // next probe position >= limc: service
+    const uint32_t mlimitc = L.mlimit - vb;
+    const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
 
-    for (;;) {
-        // ======== head: serve rare pre-conditions, then start the LUT reads ========
-        uint32_t cur, next, o;
-        for (;;) {
-            cur = L.cur;
-            next = cur + L.step;
-            o = cur - 4u - w.rb;
-            const bool pre = (next > L.mfl1) | (o > 15u) | (!YONLY && cur > w.lim);
-            if (__builtin_expect(!__any(pre), 1)) break;
-            if (pre) {
-                if (YONLY) {
-                    if (next > L.mfl1) {                 // block end / bail-out
-                        if (snk_fast_block_step(L, T, tbl, bm, slot, out, status)) return SNK_LOOP_DONE;
-                    } else {                             // long jump: re-seat the reservoir on y
-                        snk_win_init(w, arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, cur);
-                    }
-                } else {
-                    // one fully general probe: opens/closes blocks, re-seats the reservoir, walks the seam
-                    if (snk_fast_iter<false>(L, T, tbl, bm, slot, out, status)) return SNK_LOOP_DONE;
-                }
-            }
-            if (!YONLY && __all(L.yflag)) return SNK_LOOP_SWITCH;
-        }
-        uint32_t wc = __builtin_amdgcn_alignbit(w.r1, w.r0, 2u * o);
-        uint32_t s1 = lut0[(wc >> 8) & 1023u];
-        uint32_t s2e = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);   // nothing owed: unused slot
-        uint32_t nxoff = w.soff + ((w.rb + 32u - w.org) >> 2);      // arena offset of the bases [rb+32, rb+48)
-        const uint32_t olim6 = L.olimit - 6u;                       // olimit >= 12 inside an open block
-
-        // ======== steady state: one probe per trip, LUT reads for the next one already in flight ========
-        for (;;) {
-            SNK_STAMP_T(t0);
-            const uint32_t c = cur - L.base;
-            const uint32_t bit1 = 1u << (s1 & 31u);
-            // liblz4's order: put(cur-2), then read the slot of cur, then put(cur).  The LDS executes a
-            // wave's operations in issue order, so a put to the same slot is seen by the read.
-            // Only the cheap 16-bit write of the owed put goes in front of the read; its bitmap bit
-            // follows the read and is patched in by one compare.
-            tbl[s2e] = (uint16_t)(c - 2u);
-            const uint32_t e = tbl[s1];
-            const uint32_t bw = bm[s1 >> 5];
-            atomicOr(&bm[s2e >> 5], 1u << (s2e & 31u));
-            tbl[s1] = (uint16_t)c;
-            atomicOr(&bm[s1 >> 5], bit1);
-            const bool hit = (bw & bit1) != 0u;
-            const bool same = (s2e == s1);
-            const bool iscur = hit || same;
-            const bool valid = iscur || (e > c);
-            uint32_t cand = (iscur ? L.base : L.base - 65536u) + e;
-            cand = valid ? cand : cur;
-#ifdef SNK_STAMP
-            asm volatile("" :: "v"(cand));
-            SNK_STAMP_T(t1);                                  // table data arrived, candidate known
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t wd = YONLY ? snk_w32_at(arena, L.s.yoff, (int32_t)(cand - ybias))
-                                      : snk_fetch32_nobranch(L.s, cand);
-            w.nx = snk_ld4g(arena + (size_t)nxoff);
-            __builtin_amdgcn_sched_barrier(0);
-
-            const uint32_t x = wc ^ wd;
-#ifdef SNK_STAMP
-            asm volatile("" :: "v"(x));
-            __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0)
-            SNK_STAMP_T(t2);                                  // candidate window arrived
-#endif
-            const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;
-            const bool m = valid & (f >= 4u);
-            uint32_t e2 = cur + f;
-            e2 = e2 < L.mlimit ? e2 : L.mlimit;
-            const uint32_t s3 = L.nb >> 6;
-            const uint32_t nstep = m ? 1u : (s3 ? s3 : 1u);
-            const uint32_t ncur = m ? e2 : next;
-
-            // ---- next probe: reservoir + LUT reads (issued before this probe's bookkeeping) ----
-            const uint32_t nnext = ncur + nstep;
-            uint32_t no = ncur - 4u - w.rb;
-            const bool sl = (no - 16u) < 16u;
-            const uint32_t sl16 = sl ? 16u : 0u;
-            const uint32_t r0n = sl ? w.r1 : w.r0;       // w.nx (just refilled, waited for with wd)
-            const uint32_t r1n = sl ? w.nx : w.r1;
-            no -= sl16;
-            const uint32_t nwc = __builtin_amdgcn_alignbit(r1n, r0n, 2u * (no & 15u));
-            const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
-            const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
-            __builtin_amdgcn_sched_barrier(0);           // keep the LUT reads in front of the bookkeeping
-#ifdef SNK_STAMP
-            SNK_STAMP_T(t3);                                  // next LUT reads issued
-#endif
-
-            // ---- bookkeeping of this probe, in the shadow of the LUT reads ----
-            const uint32_t anchor0 = L.anchor, op0 = L.op;
-            uint32_t lit = cur - anchor0;
-            const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;
-            uint32_t b = eq < lit ? eq : lit;
-            b = b < cand ? b : cand;
-            lit -= b;
-            const uint32_t mc = e2 - (cur - b) - 4u;
-            const uint32_t opn = op0 + lit + 3u;
-            // rare: back-extension reaches 4 (b+11 >= 15), match reaches 12 (f+3 >= 15), a length needs
-            // extension bytes (>= 15), or the output budget is at risk.  (A match that ends the block
-            // needs no special case: the head closes the block from the committed op/anchor.)
-            uint32_t mx = lit > mc ? lit : mc;
-            { const uint32_t t1 = b + 11u, t2 = f + 3u; const uint32_t t3 = t1 > t2 ? t1 : t2; mx = mx > t3 ? mx : t3; }
-            const bool rare = m & ((mx >= 15u) | (opn > olim6));
-            SNK_TRACE_REC(3u, cur, cand, (f << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), cur);
-            SNK_TRACE_REC(5u, wc, w.rb, nxoff - w.soff, cur);
-            const bool pre = (nnext > L.mfl1) | (no > 15u) | (!YONLY && ncur > w.lim);
-            L.op = m ? opn : op0;
-            L.anchor = m ? e2 : anchor0;
-            L.step = nstep;
-            L.nb = m ? 63u : L.nb + 1u;
-            w.r0 = r0n; w.r1 = r1n; w.rb += sl16; nxoff += sl16 >> 2;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare | pre) != 0ull, 0)) {
-                L.cur = ncur; L.pending = m;
-                if (rare) snk_fast_match_slow(L, cur, cand, f, anchor0, op0);
-                // restore the head invariant: the reservoir may just have slid
-                w.nx = snk_ld4g(arena + (size_t)nxoff);
-                break;                                   // the head re-derives everything from L
-            }
-            cur = ncur; next = nnext; wc = nwc; s1 = ns1; s2e = m ? ns2 : (SNK_FSLOTS - 1u);
-#ifdef SNK_STAMP
-            asm volatile("" :: "v"(s1), "v"(s2e));            // forces the LUT data to have arrived
-            SNK_STAMP_T(t4);
-            acc1 += t1 - t0; acc2 += t2 - t1; acc3 += t3 - t2; acc4 += t4 - t3; iters++;
-            if (YONLY && blockIdx.x == 0 && threadIdx.x == 0 && (iters & 1023) == 0) {
-                snk_stamp_buf[0] = acc1; snk_stamp_buf[1] = acc2; snk_stamp_buf[2] = acc3; snk_stamp_buf[3] = acc4; snk_stamp_buf[4] = iters;
-            }
-#endif
-        }
+    uint32_t c = L.cur - vb, anchor_c = L.anchor - vb, op = L.op;
+    uint32_t r0 = w.r0, r1 = w.r1, r2 = w.nx;
+    uint32_t rbc = w.rb + 4u - vb;                                // c - rbc = offset of the cursor window in (r0, r1, r2)
+    uint32_t nxoff = w.soff + ((w.rb + 32u - w.org) >> 2);        // arena offset of the bases [rb+32, rb+48)
+    uint32_t wc, s1, s2;
+    {   // window and slots of the first probe (slides the reservoir if the cursor has left r0)
+        const uint32_t no = c - rbc;
+        const bool sl = no >= 16u;
+        r0 = sl ? r1 : r0; r1 = sl ? r2 : r1;
+        rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
+        wc = __builtin_amdgcn_alignbit(r1, r0, 2u * no);
+        s1 = lut0[(wc >> 8) & 1023u];
+        s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
     }
+    uint32_t t; bool valid;
+    for (;;) {
+        // ---- table: read slot(cur) + its bitmap word (the OR returns the old word), owed put, put(cur) ----
+        const uint32_t bit1 = s1 & 31u;
+        const uint32_t e = tbl[s1];
+        const uint32_t bw = atomicOr(&bm[s1 >> 5], 1u << bit1);
+        tbl[s2] = (uint16_t)(c - 2u);
+        atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+        tbl[s1] = (uint16_t)c;
+        t = e + (((bw >> bit1) & 1u) << 16);
+        t = (s2 == s1) ? 65534u + c : t;                          // the owed put went to the same slot: candidate cur-2
+        valid = t > c;                                            // this block: t >= 65536 > c; previous block: e > c
+
+        // ---- candidate window (global, L1) and the reservoir refill, in flight together ----
+        const bool inx = (int32_t)t < sx;
+        const uint32_t tt = t + (inx ? kx : 0u);
+        const uint64_t v = snk_ld8g(arena + (size_t)((inx ? xoffB : yoffB) + (tt >> 2)));
+        r2 = snk_ld4g(arena + (size_t)nxoff);
+        const bool straddle = valid & ((uint32_t)((int32_t)t - sx) < 15u);
+        const uint32_t lit = c - anchor_c;
+        const uint32_t wd = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, 2u * (tt & 3u));
+
+        // ---- compare, next cursor ----
+        const uint32_t x = wc ^ wd;
+        const uint32_t r = snk_ffbl(x >> 8);                      // 2 * equal bases from cur; 0xFFFFFFFF: all 12
+        const bool m = valid & (r >= 8u);
+        uint32_t e2 = c + (r >> 1);                               // all 12 equal: huge, clamped to mlimitc >= limc -> exit
+        e2 = e2 < mlimitc ? e2 : mlimitc;
+        const uint32_t ncur = m ? e2 : c + 1u;
+
+        // ---- window and slot LUT reads of the next probe ----
+        const uint32_t no = ncur - rbc;                           // 0..27
+        const bool sl = no >= 16u;
+        const uint32_t lo = sl ? r1 : r0, hi = sl ? r2 : r1;
+        const uint32_t nwc = __builtin_amdgcn_alignbit(hi, lo, 2u * no);
+        const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
+        const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
+
+        // ---- this probe's accounting, in the shadow of the LUT reads ----
+        const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;   // equal bases before cur, 0..4
+        uint32_t b = eq < lit ? eq : lit;
+        { const uint32_t cand = (uint32_t)(T0 + (int32_t)t); b = b < cand ? b : cand; }          // not before the stream start
+        const uint32_t opn = op + (lit - b) + 3u;                 // token + literals + offset, no extension bytes
+        // service: literal run >= 15, back-extension reaches 4 (may go on), output budget near
+        int32_t mx = (int32_t)(b + 11u) > (int32_t)lit ? (int32_t)(b + 11u) : (int32_t)lit;
+        { const int32_t z = (int32_t)opn - olimZ + 14; mx = mx > z ? mx : z; }      // opn > olimit - 70
+        const bool svc = (mx >= 15) | (ncur >= limc) | straddle;
+        SNK_TRACE_REC(3u, vb + c, (uint32_t)(T0 + (int32_t)t), (r << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), vb + c);
+        if (__builtin_amdgcn_ballot_w64(svc) != 0ull) break;
+
+        // ---- commit ----
+        op = m ? opn : op; anchor_c = m ? ncur : anchor_c;
+        r0 = lo; r1 = hi; rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
+        c = ncur; wc = nwc; s1 = ns1; s2 = m ? ns2 : (SNK_FSLOTS - 1u);
+    }
+    // hand every lane over in the state "table operations of the probe at c done, match not evaluated"
+    L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
+    w.rb = 0x80000000u;                                           // reservoir not kept: the head re-seats it
+    snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
 }
 
 // One chain of the 2-bit kernel.  `lds` = this chain's 1904 bytes, `slot` = the
@@ -506,15 +394,25 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
     L.blocks_left = (L.n >> 16) + 4u;
     L.iend = 0; L.blen = 0; L.first = true; L.in_block = false;
     L.cur = 0; L.step = 1; L.nb = 64; L.anchor = 0; L.op = 0;
-    L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos; L.endcode = 0;     // mfl1 = 0: first iteration opens a block
-    L.pending = false; L.yflag = false;
-    L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u; L.w.r0 = L.w.r1 = L.w.nx = 0u;
+    L.k3 = (0u - lx) & 3u;
+    L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos - L.k3; L.endcode = 0;     // mfl1 = 0: first iteration opens a block
+    L.pending = false;
+    L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0x80000000u; L.w.lim = 0u; L.w.r0 = L.w.r1 = L.w.nx = 0u;
 
     for (;;) {
-        int r;
-        if (__all(L.yflag)) r = snk_fast_loop<true>(L, T, tbl, bm, slot, out, status);    // deep inside y, to the end
-        else                r = snk_fast_loop<false>(L, T, tbl, bm, slot, out, status);   // seam-aware
-        if (r == SNK_LOOP_DONE) break;
+        // ---- head: general probes and reservoir re-seats until every lane of the wave is eligible ----
+        for (;;) {
+            bool ok = snk_fast_eligible(L);
+            if (!ok && L.cur + L.step <= L.mfl1) {           // inside a block: can the reservoir be re-seated?
+                const uint32_t cur = L.cur;
+                if (cur >= lx + 4u)                        snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
+                else if (cur >= 4u && cur + 12u <= lx)     snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
+                ok = snk_fast_eligible(L);
+            }
+            if (__builtin_expect(!__any(!ok), 1)) break;
+            if (!ok && snk_fast_iter(L, T, tbl, bm, slot, out, status)) return;
+        }
+        snk_fast_steady(L, tbl, bm, slot);
     }
 }
 
@@ -553,17 +451,20 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         const uint32_t spos = T.snap_pos[xi];
         const bool use = (snp == 0) && (spos != 0u);
         const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
+        // offsets from the virtual base of the block before spos (k3 = -lx mod 4, see snk_fast_steady)
+        const uint32_t k3 = (0u - T.len[xi]) & 3u;
+        const uint32_t pvb = spos - 65536u - k3;
         for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
-            uint32_t v = 0u;
+            uint32_t v = k3 * 0x10001u;                       // stream start: every slot holds position 0
             if (use) {
                 const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
-                const uint32_t lo = (a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u;   // previous block, else dead
-                const uint32_t hi = (a1 + 65536u >= spos) ? (a1 & 0xFFFFu) : 0u;
+                const uint32_t lo = (a0 != 0u && a0 + 65536u >= spos) ? a0 - pvb : 0u;   // previous block, else dead
+                const uint32_t hi = (a1 != 0u && a1 + 65536u >= spos) ? a1 - pvb : 0u;
                 v = lo | (hi << 16);
             }
             ((uint32_t *)dst)[t] = v;
         }
-        // no snapshot: stream start, every slot holds position 0 "written in this block"
+        // no snapshot: position 0 counts as "written in this block"
         for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;
     }
     __syncthreads();

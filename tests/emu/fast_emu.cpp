@@ -35,7 +35,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     }
     std::vector<uint8_t> ok((size_t)n, 0);
     std::vector<uint32_t> poff((size_t)n, 0), len((size_t)n), spos((size_t)n);
-    size_t ptot = 4 * SNK_PAD;
+    size_t ptot = SNK_ARENA_SLACK;
     for (int g = 0; g < n; ++g) {
         len[g] = (uint32_t)lens[g];
         bool pure = lens[g] > 0;
@@ -47,7 +47,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         if (pure) { poff[g] = (uint32_t)ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; }
         spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
     }
-    ptot += 65536;                                   // slack behind the last sequence
+    ptot += SNK_ARENA_SLACK;
     std::vector<uint8_t> arena(ptot, 0);
     for (int g = 0; g < n; ++g) {
         if (!ok[g]) continue;
