@@ -27,6 +27,7 @@ struct snk_ctx_impl {
     std::string err;
 
     // options
+    bool fast_asm = true;            // 0 = the C++ statement of the 2-bit kernel's steady loop (cross-checks)
     int fast_lanes = 21, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
@@ -157,7 +158,8 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", chains);
-        const void *fk = singles ? (const void *)snk_fast_singles_kernel : (const void *)snk_fast_kernel;
+        const void *fk = singles ? (const void *)snk_fast_singles_kernel
+                                 : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel;
         HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {   // the kernel addresses its slot LUT at LDS offset 0: that holds only without static LDS
             hipFuncAttributes fa;
@@ -169,8 +171,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         if (singles)
             hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st,
                                T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
-        else
+        else if (c->fast_asm)
             hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st,
+                               T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+        else
+            hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st,
                                T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
@@ -413,6 +418,8 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "fast_waves") {
         if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "fast_waves must be 1..16");
         c->fast_waves = (int)value;
+    } else if (k == "fast_asm") {
+        c->fast_asm = value != 0;
     } else if (k == "gen_chains") {
         if (value < 1 || value > 9) return fail(c, SNK_E_ARG, "gen_chains must be 1..9");
         c->gen_chains = (int)value;

@@ -275,7 +275,11 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 // slot(cur) is issued first (it heads the dependent chain) and the case slot(cur-2) == slot(cur)
 // is patched in by one select; the bitmap word comes back from the OR that sets the bit of cur
 // (ds_or_rtn_b32).
-__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, uint32_t *bm, const uint16_t *slot)
+//
+// ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
+// statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
+template <bool ASM>
+__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off)
 {
     SnkWin &w = L.w;
     snk_g8 *const arena = L.s.arena;
@@ -293,7 +297,6 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
     const int32_t sx = (int32_t)L.s.lx - 11 - T0;                 // t < sx: window inside x; t >= sx + 15: inside y
     const uint32_t limw = w.lim == 0xFFFFFFFFu ? w.lim : w.lim + 1u;
     const uint32_t limc = (L.mfl1 < limw ? L.mfl1 : limw) - vb;   // next probe position >= limc: service
-    const uint32_t mlimitc = L.mlimit - vb;
     const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
 
     uint32_t c = L.cur - vb, anchor_c = L.anchor - vb, op = L.op;
@@ -311,6 +314,117 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
         s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
     }
     uint32_t t; bool valid;
+#ifndef SNK_HOST_EMU
+    if (ASM) {
+        uint32_t lit;
+        uint64_t sv, ss, sm, sl, st;                                  // wave masks: valid, straddle, match, slide, limit
+        const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
+        // Temporaries live in v90..v126 (clobbered).  One VALU instruction of a lone wave issues every
+        // 4 cycles, so the schedule is: slot(cur) read first; owed put, refill load and everything that
+        // does not depend on the table in its shadow; candidate load; compare; next window + LUT reads;
+        // accounting in the LUT shadow; commit.  gfx950 needs 2 wait states between a VALU that writes
+        // an SGPR/VCC and a VALU that reads it: every v_cmp below has two instructions behind it.
+        asm volatile(
+            "1:\n\t"
+            "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t"
+            "ds_read_u16 v91, v90\n\t"
+            "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t"
+            "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t"
+            "v_lshlrev_b32_e64 v93, %[s1], 1\n\t"
+            "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t"
+            "global_load_dword v108, %[nxoff], %[arena]\n\t"
+            "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t"
+            "v_add_u32_e32 v96, -2, %[c]\n\t"
+            "ds_write_b16 v95, v96\n\t"
+            "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t"
+            "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t"
+            "v_lshlrev_b32_e64 v98, %[s2], 1\n\t"
+            "ds_or_b32 v97, v98 offset:1792\n\t"
+            "ds_write_b16 v90, %[c]\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t"
+            "v_add_u32_e32 v99, 0xfffe, %[c]\n\t"
+            "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t"
+            "v_add_u32_e32 v112, 1, %[c]\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            "v_bfe_u32 %[t], v94, %[s1], 1\n\t"
+            "v_lshl_add_u32 %[t], %[t], 16, v91\n\t"
+            "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t"
+            "v_sub_u32_e32 v100, %[t], %[sx]\n\t"
+            "v_ashrrev_i32_e32 v101, 31, v100\n\t"
+            "v_bfi_b32 v102, v101, %[xoffB], %[yoffB]\n\t"
+            "v_and_b32_e32 v101, %[kx], v101\n\t"
+            "v_add_u32_e32 v103, %[t], v101\n\t"
+            "v_lshrrev_b32_e32 v104, 2, v103\n\t"
+            "v_add_u32_e32 v104, v104, v102\n\t"
+            "global_load_dwordx2 v[106:107], v104, %[arena]\n\t"
+            "v_cmp_gt_u32_e64 %[sv], %[t], %[c]\n\t"
+            "v_and_b32_e32 v109, 3, v103\n\t"
+            "v_lshlrev_b32_e32 v109, 1, v109\n\t"
+            "v_cmp_gt_u32_e32 vcc, 15, v100\n\t"
+            "s_and_b64 %[ss], vcc, %[sv]\n\t"
+            "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
+            "v_add_u32_e32 v111, %[T0], %[t]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "v_alignbit_b32 v113, v107, v106, v109\n\t"
+            "v_xor_b32_e32 v113, v113, %[wc]\n\t"
+            "v_lshrrev_b32_e32 v114, 8, v113\n\t"
+            "v_ffbl_b32_e32 v114, v114\n\t"
+            "v_and_b32_e32 v114, v114, v110\n\t"
+            "v_cmp_lt_u32_e64 %[sm], 7, v114\n\t"
+            "v_lshrrev_b32_e32 v115, 1, v114\n\t"
+            "v_add_u32_e32 v115, v115, %[c]\n\t"
+            "v_cndmask_b32_e64 %[c], v112, v115, %[sm]\n\t"
+            "v_sub_u32_e32 v116, %[c], %[rbc]\n\t"
+            "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t"
+            "v_lshlrev_b32_e32 v116, 1, v116\n\t"
+            "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t"
+            "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t"
+            "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t"
+            "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t"
+            "v_lshrrev_b32_e32 v117, 7, %[wc]\n\t"
+            "v_and_b32_e32 v117, 0x7fe, v117\n\t"
+            "ds_read_u16 %[s1], v117\n\t"
+            "v_lshrrev_b32_e32 v118, 3, %[wc]\n\t"
+            "v_and_b32_e32 v118, 0x7fe, v118\n\t"
+            "ds_read_u16 v119, v118\n\t"
+            "v_ffbh_u32_e32 v120, v120\n\t"
+            "v_lshrrev_b32_e32 v120, 1, v120\n\t"
+            "v_min3_u32 v120, v120, %[lit], v111\n\t"
+            "v_sub_u32_e32 v121, %[lit], v120\n\t"
+            "v_add3_u32 v122, %[op], v121, 3\n\t"
+            "v_add_u32_e32 v123, 11, v120\n\t"
+            "v_sub_u32_e32 v124, v122, %[oz]\n\t"
+            "v_max3_i32 v125, v123, %[lit], v124\n\t"
+            "v_cmp_lt_i32_e32 vcc, 14, v125\n\t"
+            "v_cmp_ge_u32_e64 %[st], %[c], %[limc]\n\t"
+            "s_or_b64 vcc, vcc, %[st]\n\t"
+            "s_or_b64 vcc, vcc, %[ss]\n\t"
+            "s_cbranch_vccnz 2f\n\t"
+            "v_cndmask_b32_e64 %[op], %[op], v122, %[sm]\n\t"
+            "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t"
+            "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t"
+            "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t"
+            "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cndmask_b32_e64 %[s2], %[dm], v119, %[sm]\n\t"
+            "s_branch 1b\n\t"
+            "2:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1),
+              [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op),
+              [t] "=&v"(t), [lit] "=&v"(lit),
+              [sv] "=&s"(sv), [ss] "=&s"(ss), [sm] "=&s"(sm), [sl] "=&s"(sl), [st] "=&s"(st)
+            : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB),
+              [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u),
+              [arena] "s"(arena)
+            : "memory", "vcc", "scc",
+              "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103",
+              "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+              "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+        c = lit + anchor_c;                                           // the loop keeps the NEXT cursor in c
+        valid = t > c;
+    } else
+#endif
     for (;;) {
         // ---- table: read slot(cur) + its bitmap word (the OR returns the old word), owed put, put(cur) ----
         const uint32_t bit1 = s1 & 31u;
@@ -336,8 +450,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
         const uint32_t x = wc ^ wd;
         const uint32_t r = snk_ffbl(x >> 8);                      // 2 * equal bases from cur; 0xFFFFFFFF: all 12
         const bool m = valid & (r >= 8u);
-        uint32_t e2 = c + (r >> 1);                               // all 12 equal: huge, clamped to mlimitc >= limc -> exit
-        e2 = e2 < mlimitc ? e2 : mlimitc;
+        const uint32_t e2 = c + (r >> 1);                         // all 12 equal: huge; past the match limit: >= limc -> service
         const uint32_t ncur = m ? e2 : c + 1u;
 
         // ---- window and slot LUT reads of the next probe ----
@@ -373,8 +486,9 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
 
 // One chain of the 2-bit kernel.  `lds` = this chain's 1904 bytes, `slot` = the
 // workgroup's 5-mer -> slot LUT.
+template <bool ASM>
 __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob job,
-                                               uint8_t *lds, const uint16_t *slot,
+                                               uint8_t *lds, uint32_t lds_off, const uint16_t *slot,
                                                uint32_t *out, uint32_t *status)
 {
     uint16_t *tbl = (uint16_t *)lds;
@@ -412,11 +526,12 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
             if (__builtin_expect(!__any(!ok), 1)) break;
             if (!ok && snk_fast_iter(L, T, tbl, bm, slot, out, status)) return;
         }
-        snk_fast_steady(L, tbl, bm, slot);
+        snk_fast_steady<ASM>(L, tbl, bm, slot, lds_off);
     }
 }
 
 // grid: one workgroup per `lanes*waves` jobs.  dynamic LDS = 2 KiB LUT + 1904 B per chain.
+template <bool ASM>
 __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
                                                      uint32_t lanes, uint32_t *out, uint32_t *status)
 {
@@ -436,7 +551,8 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     const uint32_t c = lane * waves + wave;
     const uint32_t j = blockIdx.x * chains + c;
     const bool active = lane < lanes && j < n_jobs;
-    uint8_t *mine = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + (lane < lanes ? lane : 0u)) * SNK_FCHAIN_B;
+    const uint32_t mine_off = SNK_FLUT_B + (wave * lanes + (lane < lanes ? lane : 0u)) * SNK_FCHAIN_B;   // LDS address: dynamic LDS starts at 0
+    uint8_t *mine = snk_lds8 + mine_off;
 
     SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
     if (active) job = jobs[j];
@@ -469,14 +585,23 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     }
     __syncthreads();
 
-    if (active) snk_fast_chain(T, job, mine, slot, out, status);
+    if (active) snk_fast_chain<ASM>(T, job, mine, mine_off, slot, out, status);
 }
 
+#ifndef SNK_HOST_EMU
 // phase B: ordered pairs (the dominant kernel of the bench)
 __global__ void snk_fast_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                 uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body(T, jobs, n_jobs, lanes, out, status);
+    snk_fast_kernel_body<true>(T, jobs, n_jobs, lanes, out, status);
+}
+
+// the same with the C++ statement of the steady loop (option fast_asm = 0: cross-check of the
+// hand-scheduled loop in the tests, A/B timing)
+__global__ void snk_fast_cxx_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                    uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fast_kernel_body<false>(T, jobs, n_jobs, lanes, out, status);
 }
 
 // phase A: single sequences + prefix snapshots at upload (same code, own symbol so that profiles
@@ -484,5 +609,6 @@ __global__ void snk_fast_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs
 __global__ void snk_fast_singles_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
                                         uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body(T, jobs, n_jobs, lanes, out, status);
+    snk_fast_kernel_body<true>(T, jobs, n_jobs, lanes, out, status);
 }
+#endif

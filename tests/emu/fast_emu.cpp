@@ -67,14 +67,14 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         singles[g] = 0;
         if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
         SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
-        snk_fast_kernel_body(T, &jb, 1u, 1u, singles, status.data());
+        snk_fast_kernel_body<false>(T, &jb, 1u, 1u, singles, status.data());
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             pairs[(size_t)i * n + j] = 0;
             if (!ok[i] || !ok[j] || lens[i] + lens[j] <= SNK_BLOCK) continue;
             SnkJob jb; jb.xi = i; jb.yi = j; jb.out_idx = (uint32_t)((size_t)i * n + j); jb.snap = 0;
-            snk_fast_kernel_body(T, &jb, 1u, 1u, pairs, status.data());
+            snk_fast_kernel_body<false>(T, &jb, 1u, 1u, pairs, status.data());
         }
     return (int)status[0];
 }

@@ -199,6 +199,32 @@ def test_blocks_ending_in_short_matches(hip, oracle_mod):
     assert np.array_equal(p, exp_p), np.flatnonzero(p != exp_p)
 
 
+def test_hand_scheduled_steady_loop_equals_its_cxx_statement(hip, oracle_mod):
+    """The 2-bit kernel's steady loop exists twice: hand-scheduled gfx950 code (the product) and the
+    C++ statement of the same dataflow (option fast_asm=0; also what tests/test_kernel_emu.py runs
+    on the CPU).  Both must equal the oracle on inputs that hit every service exit: block ends,
+    seams at every phase of len(x) mod 4, long matches, long literal runs, stream starts, tandem
+    repeats (owed put into the slot being read), relatives."""
+    o = oracle_mod
+    rng = np.random.default_rng(99)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    anc = o.lcg_genome(61, 150001)
+    seqs = [o.lcg_genome(51 + k, n) for k, n in enumerate([100001, 100002, 100003, 65530, 65537, 131075, 70000, 40000])]
+    seqs += [anc, o.lcg_mutant(anc, 3), _tandem(rng, 140000, 37, 0.0), _tandem(rng, 150003, 900, 0.02),
+             np.frombuffer(b"A" * 100000, dtype=np.uint8), np.frombuffer(b"AC" * 50001, dtype=np.uint8),
+             rng.choice(acgt, 90000, p=[0.85, 0.05, 0.05, 0.05]),
+             np.repeat(rng.choice(acgt, 5000), rng.integers(1, 60, 5000))[:120000].copy()]
+    exp_s = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    for asm in (1, 0):
+        with hip.HipContext(0, fast_asm=asm) as ctx:
+            ctx.upload(seqs)
+            assert ctx.num_packed == len(seqs)
+            s, p = ctx.singles(), ctx.pairs()
+        assert np.array_equal(s, exp_s), (asm, np.flatnonzero(s != exp_s))
+        assert np.array_equal(p, exp_p), (asm, np.argwhere(p != exp_p)[:8].tolist())
+
+
 def test_related_genomes_same_ancestor(hip, oracle_mod):
     o = oracle_mod
     anc = o.lcg_genome(40, 180000)

@@ -77,7 +77,7 @@ def one(seed):
     exp_s = np.array([oracle.lz4f_size(x) for x in seqs], dtype=np.uint32)
     exp_p = pairs_mt(seqs, 0, n, 16)
     bad = []
-    for opts in ({}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
+    for opts in ({}, {"fast_asm": 0}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
                  {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2}):
         with hip.HipContext(0, **opts) as ctx:
             ctx.upload(seqs)
