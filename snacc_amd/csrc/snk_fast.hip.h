@@ -317,24 +317,35 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
 #ifndef SNK_HOST_EMU
     if (ASM) {
         uint32_t lit;
-        uint64_t sv, ss, sm, sl, st;                                  // wave masks: valid, straddle, match, slide, limit
+        uint64_t sv, ss, st;                                          // wave masks: valid, straddle, limit
+        uint64_t sm = __builtin_amdgcn_ballot_w64(L.pending);         // match of the previous probe (its commit is owed)
+        uint64_t sl = 0;                                              // slide of the previous probe (none owed)
+        uint32_t opn = op;                                            // ... committing it again changes nothing
+        uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
-        // Temporaries live in v90..v126 (clobbered).  One VALU instruction of a lone wave issues every
-        // 4 cycles, so the schedule is: slot(cur) read first; owed put, refill load and everything that
-        // does not depend on the table in its shadow; candidate load; compare; next window + LUT reads;
-        // accounting in the LUT shadow; commit.  gfx950 needs 2 wait states between a VALU that writes
-        // an SGPR/VCC and a VALU that reads it: every v_cmp below has two instructions behind it.
+        // Temporaries live in v90..v126 (clobbered).  A lone wave issues one instruction every ~4.3
+        // cycles, so a trip costs (instructions on the dependent chain) x 4.3 + the three latencies
+        // (table read, candidate load, LUT read) + whatever overflows their shadows.  Schedule:
+        // slot(cur) read first, owed put in its shadow; candidate load, and in ITS shadow the commit
+        // of the previous probe (op, anchor, reservoir) and everything that does not need the window;
+        // compare; next window + LUT reads; this probe's accounting and the one exit test in the LUT
+        // shadow (kept to ~14 instructions = the LUT latency).  gfx950 needs 2 wait states between a
+        // VALU that writes an SGPR/VCC and a VALU that reads it: every v_cmp has two instructions
+        // behind it before its consumer.
         asm volatile(
             "1:\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"                              // slot of cur (the slot of cur-2 may still be in flight)
             "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t"
             "ds_read_u16 v91, v90\n\t"
             "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t"
             "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t"
             "v_lshlrev_b32_e64 v93, %[s1], 1\n\t"
             "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t"
-            "global_load_dword v108, %[nxoff], %[arena]\n\t"
-            "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t"
             "v_add_u32_e32 v96, -2, %[c]\n\t"
+            "v_add_u32_e32 v99, 0xfffe, %[c]\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
+            "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t"    // nothing owed: the unused slot
+            "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t"
             "ds_write_b16 v95, v96\n\t"
             "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t"
             "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t"
@@ -342,8 +353,6 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
             "ds_or_b32 v97, v98 offset:1792\n\t"
             "ds_write_b16 v90, %[c]\n\t"
             "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t"
-            "v_add_u32_e32 v99, 0xfffe, %[c]\n\t"
-            "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t"
             "v_add_u32_e32 v112, 1, %[c]\n\t"
             "s_waitcnt lgkmcnt(3)\n\t"
             "v_bfe_u32 %[t], v94, %[s1], 1\n\t"
@@ -357,6 +366,15 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
             "v_lshrrev_b32_e32 v104, 2, v103\n\t"
             "v_add_u32_e32 v104, v104, v102\n\t"
             "global_load_dwordx2 v[106:107], v104, %[arena]\n\t"
+            // ---- shadow of the candidate load: commit of the previous probe, refill, validity ----
+            "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t"
+            "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t"
+            "global_load_dword v108, %[nxoff], %[arena]\n\t"
+            "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t"
+            "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm]\n\t"
+            "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t"
+            "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t"
+            "v_sub_u32_e32 v124, %[op], %[oz]\n\t"
             "v_cmp_gt_u32_e64 %[sv], %[t], %[c]\n\t"
             "v_and_b32_e32 v109, 3, v103\n\t"
             "v_lshlrev_b32_e32 v109, 1, v109\n\t"
@@ -364,7 +382,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
             "s_and_b64 %[ss], vcc, %[sv]\n\t"
             "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
             "v_add_u32_e32 v111, %[T0], %[t]\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
+            "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"         // a straddling window trips the limit test
+            "s_waitcnt vmcnt(1)\n\t"
             "v_alignbit_b32 v113, v107, v106, v109\n\t"
             "v_xor_b32_e32 v113, v113, %[wc]\n\t"
             "v_lshrrev_b32_e32 v114, 8, v113\n\t"
@@ -378,6 +397,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
             "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t"
             "v_lshlrev_b32_e32 v116, 1, v116\n\t"
             "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
             "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t"
             "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t"
             "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t"
@@ -386,34 +406,24 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
             "ds_read_u16 %[s1], v117\n\t"
             "v_lshrrev_b32_e32 v118, 3, %[wc]\n\t"
             "v_and_b32_e32 v118, 0x7fe, v118\n\t"
-            "ds_read_u16 v119, v118\n\t"
+            "ds_read_u16 %[ns2], v118\n\t"
+            // ---- this probe's accounting and the exit test, in the shadow of the LUT reads ----
             "v_ffbh_u32_e32 v120, v120\n\t"
             "v_lshrrev_b32_e32 v120, 1, v120\n\t"
             "v_min3_u32 v120, v120, %[lit], v111\n\t"
             "v_sub_u32_e32 v121, %[lit], v120\n\t"
-            "v_add3_u32 v122, %[op], v121, 3\n\t"
+            "v_add3_u32 %[opn], %[op], v121, 3\n\t"
             "v_add_u32_e32 v123, 11, v120\n\t"
-            "v_sub_u32_e32 v124, v122, %[oz]\n\t"
             "v_max3_i32 v125, v123, %[lit], v124\n\t"
             "v_cmp_lt_i32_e32 vcc, 14, v125\n\t"
-            "v_cmp_ge_u32_e64 %[st], %[c], %[limc]\n\t"
+            "v_cmp_ge_u32_e64 %[st], %[c], v105\n\t"
             "s_or_b64 vcc, vcc, %[st]\n\t"
-            "s_or_b64 vcc, vcc, %[ss]\n\t"
-            "s_cbranch_vccnz 2f\n\t"
-            "v_cndmask_b32_e64 %[op], %[op], v122, %[sm]\n\t"
-            "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t"
-            "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t"
-            "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t"
-            "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cndmask_b32_e64 %[s2], %[dm], v119, %[sm]\n\t"
-            "s_branch 1b\n\t"
-            "2:\n\t"
+            "s_cbranch_vccz 1b\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1),
               [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op),
-              [t] "=&v"(t), [lit] "=&v"(lit),
-              [sv] "=&s"(sv), [ss] "=&s"(ss), [sm] "=&s"(sm), [sl] "=&s"(sl), [st] "=&s"(st)
+              [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl),
+              [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st)
             : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB),
               [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u),
               [arena] "s"(arena)
@@ -468,7 +478,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
         const uint32_t opn = op + (lit - b) + 3u;                 // token + literals + offset, no extension bytes
         // service: literal run >= 15, back-extension reaches 4 (may go on), output budget near
         int32_t mx = (int32_t)(b + 11u) > (int32_t)lit ? (int32_t)(b + 11u) : (int32_t)lit;
-        { const int32_t z = (int32_t)opn - olimZ + 14; mx = mx > z ? mx : z; }      // opn > olimit - 70
+        { const int32_t z = (int32_t)op - olimZ + 14; mx = mx > z ? mx : z; }       // op before this probe > olimit - 70
         const bool svc = (mx >= 15) | (ncur >= limc) | straddle;
         SNK_TRACE_REC(3u, vb + c, (uint32_t)(T0 + (int32_t)t), (r << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), vb + c);
         if (__builtin_amdgcn_ballot_w64(svc) != 0ull) break;
