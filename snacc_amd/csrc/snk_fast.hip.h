@@ -246,6 +246,126 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
 // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0.
 __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)__builtin_ctz(v) : 0xFFFFFFFFu; }
 
+// ---- the steady loop as gfx950 code (used by snk_fast_steady<true>) -----------------------------
+// Temporaries live in v90..v126 (clobbered).  A lone wave issues one instruction every ~4.3 cycles,
+// so a trip costs (instructions on the dependent chain) x 4.3 + the three latencies (table read,
+// candidate load, LUT read) + whatever overflows their shadows.  Schedule: slot(cur) read first,
+// owed put in its shadow; candidate load, and in ITS shadow the commit of the previous probe (op,
+// anchor, reservoir) and everything that does not need the window; compare; next window + LUT
+// reads; this probe's accounting and the one exit test in the LUT shadow (~14 instructions = the
+// LUT latency).  gfx950 needs 2 wait states between a VALU that writes an SGPR/VCC and a VALU that
+// reads it: every v_cmp has two instructions behind it before its consumer.
+// Two instantiations: DUAL (candidate window from x or y, chosen per probe; windows straddling the
+// seam trip the limit test) and YONLY (every lane's block lies wholly > 64 KiB past its seam).
+#define SNK_STEADY_TABLE \
+    "1:\n\t" \
+    "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
+    "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
+    "ds_read_u16 v91, v90\n\t" \
+    "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t" \
+    "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t" \
+    "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
+    "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t" \
+    "v_add_u32_e32 v96, -2, %[c]\n\t" \
+    "v_add_u32_e32 v99, 0xfffe, %[c]\n\t" \
+    "s_waitcnt lgkmcnt(2)\n\t" \
+    "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot */ \
+    "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
+    "ds_write_b16 v95, v96\n\t" \
+    "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t" \
+    "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
+    "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
+    "ds_or_b32 v97, v98 offset:1792\n\t" \
+    "ds_write_b16 v90, %[c]\n\t" \
+    "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
+    "v_add_u32_e32 v112, 1, %[c]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_bfe_u32 %[t], v94, %[s1], 1\n\t" \
+    "v_lshl_add_u32 %[t], %[t], 16, v91\n\t" \
+    "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t"
+// candidate window address: v104 = arena byte offset, v103 = position whose low 2 bits give the phase
+#define SNK_STEADY_ADDR_DUAL \
+    "v_sub_u32_e32 v100, %[t], %[sx]\n\t" \
+    "v_ashrrev_i32_e32 v101, 31, v100\n\t" \
+    "v_bfi_b32 v102, v101, %[xoffB], %[yoffB]\n\t" \
+    "v_and_b32_e32 v101, %[kx], v101\n\t" \
+    "v_add_u32_e32 v103, %[t], v101\n\t" \
+    "v_lshrrev_b32_e32 v104, 2, v103\n\t" \
+    "v_add_u32_e32 v104, v104, v102\n\t"
+#define SNK_STEADY_ADDR_YONLY \
+    "v_lshrrev_b32_e32 v104, 2, %[t]\n\t" \
+    "v_add_u32_e32 v104, v104, %[yoffB]\n\t"
+// shadow of the candidate load: commit of the previous probe, refill, validity (PH = phase register)
+#define SNK_STEADY_SHADOW(PH) \
+    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
+    "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
+    "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
+    "global_load_dword v108, %[nxoff], %[arena]\n\t" \
+    "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t" \
+    "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm]\n\t" \
+    "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t" \
+    "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t" \
+    "v_sub_u32_e32 v124, %[op], %[oz]\n\t" \
+    "v_cmp_gt_u32_e64 %[sv], %[t], %[c]\n\t" \
+    "v_and_b32_e32 v109, 3, " PH "\n\t" \
+    "v_lshlrev_b32_e32 v109, 1, v109\n\t" \
+    "v_add_u32_e32 v111, %[T0], %[t]\n\t" \
+    "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
+#define SNK_STEADY_STRADDLE                             /* a straddling window trips the limit test */ \
+    "v_cmp_gt_u32_e32 vcc, 15, v100\n\t" \
+    "s_and_b64 %[ss], vcc, %[sv]\n\t" \
+    "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
+// compare, next cursor, next window + LUT reads, accounting, exit test (LIM = limit register)
+#define SNK_STEADY_REST(LIM) \
+    "s_waitcnt vmcnt(1)\n\t" \
+    "v_alignbit_b32 v113, v107, v106, v109\n\t" \
+    "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
+    "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
+    "v_ffbl_b32_e32 v114, v114\n\t" \
+    "v_and_b32_e32 v114, v114, v110\n\t" \
+    "v_cmp_lt_u32_e64 %[sm], 7, v114\n\t" \
+    "v_lshrrev_b32_e32 v115, 1, v114\n\t" \
+    "v_add_u32_e32 v115, v115, %[c]\n\t" \
+    "v_cndmask_b32_e64 %[c], v112, v115, %[sm]\n\t" \
+    "v_sub_u32_e32 v116, %[c], %[rbc]\n\t" \
+    "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t" \
+    "v_lshlrev_b32_e32 v116, 1, v116\n\t" \
+    "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t" \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t" \
+    "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t" \
+    "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t" \
+    "v_lshrrev_b32_e32 v117, 7, %[wc]\n\t" \
+    "v_and_b32_e32 v117, 0x7fe, v117\n\t" \
+    "ds_read_u16 %[s1], v117\n\t" \
+    "v_lshrrev_b32_e32 v118, 3, %[wc]\n\t" \
+    "v_and_b32_e32 v118, 0x7fe, v118\n\t" \
+    "ds_read_u16 %[ns2], v118\n\t" \
+    "v_ffbh_u32_e32 v120, v120\n\t" \
+    "v_lshrrev_b32_e32 v120, 1, v120\n\t" \
+    "v_min3_u32 v120, v120, %[lit], v111\n\t" \
+    "v_sub_u32_e32 v121, %[lit], v120\n\t" \
+    "v_add3_u32 %[opn], %[op], v121, 3\n\t" \
+    "v_add_u32_e32 v123, 11, v120\n\t" \
+    "v_max3_i32 v125, v123, %[lit], v124\n\t" \
+    "v_cmp_lt_i32_e32 vcc, 14, v125\n\t" \
+    "v_cmp_ge_u32_e64 %[st], %[c], " LIM "\n\t" \
+    "s_or_b64 vcc, vcc, %[st]\n\t" \
+    "s_cbranch_vccz 1b\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define SNK_STEADY_OPERANDS \
+    : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
+      [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
+      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), \
+      [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st) \
+    : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
+      [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
+      [arena] "s"(arena) \
+    : "memory", "vcc", "scc", \
+      "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+      "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
+      "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126"
+
 // A lane may run the steady loop when its next probe is an ordinary one: inside an open block
 // that has not bailed out, search step 1, literal run and output budget far from their rare
 // ranges, cursor served by the reservoir's source.
@@ -323,114 +443,13 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
         uint32_t opn = op;                                            // ... committing it again changes nothing
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
-        // Temporaries live in v90..v126 (clobbered).  A lone wave issues one instruction every ~4.3
-        // cycles, so a trip costs (instructions on the dependent chain) x 4.3 + the three latencies
-        // (table read, candidate load, LUT read) + whatever overflows their shadows.  Schedule:
-        // slot(cur) read first, owed put in its shadow; candidate load, and in ITS shadow the commit
-        // of the previous probe (op, anchor, reservoir) and everything that does not need the window;
-        // compare; next window + LUT reads; this probe's accounting and the one exit test in the LUT
-        // shadow (kept to ~14 instructions = the LUT latency).  gfx950 needs 2 wait states between a
-        // VALU that writes an SGPR/VCC and a VALU that reads it: every v_cmp has two instructions
-        // behind it before its consumer.
-        asm volatile(
-            "1:\n\t"
-            "s_waitcnt lgkmcnt(1)\n\t"                              // slot of cur (the slot of cur-2 may still be in flight)
-            "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t"
-            "ds_read_u16 v91, v90\n\t"
-            "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t"
-            "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t"
-            "v_lshlrev_b32_e64 v93, %[s1], 1\n\t"
-            "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t"
-            "v_add_u32_e32 v96, -2, %[c]\n\t"
-            "v_add_u32_e32 v99, 0xfffe, %[c]\n\t"
-            "s_waitcnt lgkmcnt(2)\n\t"
-            "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t"    // nothing owed: the unused slot
-            "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t"
-            "ds_write_b16 v95, v96\n\t"
-            "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t"
-            "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t"
-            "v_lshlrev_b32_e64 v98, %[s2], 1\n\t"
-            "ds_or_b32 v97, v98 offset:1792\n\t"
-            "ds_write_b16 v90, %[c]\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t"
-            "v_add_u32_e32 v112, 1, %[c]\n\t"
-            "s_waitcnt lgkmcnt(3)\n\t"
-            "v_bfe_u32 %[t], v94, %[s1], 1\n\t"
-            "v_lshl_add_u32 %[t], %[t], 16, v91\n\t"
-            "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t"
-            "v_sub_u32_e32 v100, %[t], %[sx]\n\t"
-            "v_ashrrev_i32_e32 v101, 31, v100\n\t"
-            "v_bfi_b32 v102, v101, %[xoffB], %[yoffB]\n\t"
-            "v_and_b32_e32 v101, %[kx], v101\n\t"
-            "v_add_u32_e32 v103, %[t], v101\n\t"
-            "v_lshrrev_b32_e32 v104, 2, v103\n\t"
-            "v_add_u32_e32 v104, v104, v102\n\t"
-            "global_load_dwordx2 v[106:107], v104, %[arena]\n\t"
-            // ---- shadow of the candidate load: commit of the previous probe, refill, validity ----
-            "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t"
-            "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t"
-            "global_load_dword v108, %[nxoff], %[arena]\n\t"
-            "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t"
-            "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm]\n\t"
-            "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t"
-            "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t"
-            "v_sub_u32_e32 v124, %[op], %[oz]\n\t"
-            "v_cmp_gt_u32_e64 %[sv], %[t], %[c]\n\t"
-            "v_and_b32_e32 v109, 3, v103\n\t"
-            "v_lshlrev_b32_e32 v109, 1, v109\n\t"
-            "v_cmp_gt_u32_e32 vcc, 15, v100\n\t"
-            "s_and_b64 %[ss], vcc, %[sv]\n\t"
-            "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
-            "v_add_u32_e32 v111, %[T0], %[t]\n\t"
-            "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"         // a straddling window trips the limit test
-            "s_waitcnt vmcnt(1)\n\t"
-            "v_alignbit_b32 v113, v107, v106, v109\n\t"
-            "v_xor_b32_e32 v113, v113, %[wc]\n\t"
-            "v_lshrrev_b32_e32 v114, 8, v113\n\t"
-            "v_ffbl_b32_e32 v114, v114\n\t"
-            "v_and_b32_e32 v114, v114, v110\n\t"
-            "v_cmp_lt_u32_e64 %[sm], 7, v114\n\t"
-            "v_lshrrev_b32_e32 v115, 1, v114\n\t"
-            "v_add_u32_e32 v115, v115, %[c]\n\t"
-            "v_cndmask_b32_e64 %[c], v112, v115, %[sm]\n\t"
-            "v_sub_u32_e32 v116, %[c], %[rbc]\n\t"
-            "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t"
-            "v_lshlrev_b32_e32 v116, 1, v116\n\t"
-            "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
-            "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t"
-            "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t"
-            "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t"
-            "v_lshrrev_b32_e32 v117, 7, %[wc]\n\t"
-            "v_and_b32_e32 v117, 0x7fe, v117\n\t"
-            "ds_read_u16 %[s1], v117\n\t"
-            "v_lshrrev_b32_e32 v118, 3, %[wc]\n\t"
-            "v_and_b32_e32 v118, 0x7fe, v118\n\t"
-            "ds_read_u16 %[ns2], v118\n\t"
-            // ---- this probe's accounting and the exit test, in the shadow of the LUT reads ----
-            "v_ffbh_u32_e32 v120, v120\n\t"
-            "v_lshrrev_b32_e32 v120, 1, v120\n\t"
-            "v_min3_u32 v120, v120, %[lit], v111\n\t"
-            "v_sub_u32_e32 v121, %[lit], v120\n\t"
-            "v_add3_u32 %[opn], %[op], v121, 3\n\t"
-            "v_add_u32_e32 v123, 11, v120\n\t"
-            "v_max3_i32 v125, v123, %[lit], v124\n\t"
-            "v_cmp_lt_i32_e32 vcc, 14, v125\n\t"
-            "v_cmp_ge_u32_e64 %[st], %[c], v105\n\t"
-            "s_or_b64 vcc, vcc, %[st]\n\t"
-            "s_cbranch_vccz 1b\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1),
-              [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op),
-              [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl),
-              [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st)
-            : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB),
-              [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u),
-              [arena] "s"(arena)
-            : "memory", "vcc", "scc",
-              "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103",
-              "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
-              "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+        // every lane's block wholly > 64 KiB past its seam (no t can land in x or on the seam)?
+        if (__all(sx + 15 <= 0))
+            asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
+                         SNK_STEADY_OPERANDS);
+        else
+            asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW("v103") SNK_STEADY_STRADDLE SNK_STEADY_REST("v105")
+                         SNK_STEADY_OPERANDS);
         c = lit + anchor_c;                                           // the loop keeps the NEXT cursor in c
         valid = t > c;
     } else
