@@ -257,6 +257,40 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 // reads it: every v_cmp has two instructions behind it before its consumer.
 // Two instantiations: DUAL (candidate window from x or y, chosen per probe; windows straddling the
 // seam trip the limit test) and YONLY (every lane's block lies wholly > 64 KiB past its seam).
+// diagnostic builds only (-DSNK_PAD_x): 4 independent VALU instructions at one point of the loop;
+// the trip time grows by ~17 cycles where issue is on the critical path and not at all inside an
+// under-filled latency shadow (tools/gpu_padsweep.sh).
+#ifndef SNK_PADN
+#define SNK_PADN 4
+#endif
+#define SNK_STR2(x) #x
+#define SNK_STR(x) SNK_STR2(x)
+#define SNK_PAD4 ".rept " SNK_STR(SNK_PADN) "\n\tv_mov_b32_e32 v127, v127\n\t.endr\n\t"
+#ifdef SNK_PAD_A
+#define SNK_PADA SNK_PAD4
+#else
+#define SNK_PADA
+#endif
+#ifdef SNK_PAD_B
+#define SNK_PADB SNK_PAD4
+#else
+#define SNK_PADB
+#endif
+#ifdef SNK_PAD_C
+#define SNK_PADC SNK_PAD4
+#else
+#define SNK_PADC
+#endif
+#ifdef SNK_PAD_D
+#define SNK_PADD SNK_PAD4
+#else
+#define SNK_PADD
+#endif
+#ifdef SNK_PAD_E
+#define SNK_PADE SNK_PAD4
+#else
+#define SNK_PADE
+#endif
 #define SNK_STEADY_TABLE \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
@@ -265,7 +299,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t" \
     "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
-    "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t" \
+    "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t" SNK_PADA \
     "v_add_u32_e32 v96, -2, %[c]\n\t" \
     "v_add_u32_e32 v99, 0xfffe, %[c]\n\t" \
     "s_waitcnt lgkmcnt(2)\n\t" \
@@ -282,7 +316,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "s_waitcnt lgkmcnt(3)\n\t" \
     "v_bfe_u32 %[t], v94, %[s1], 1\n\t" \
     "v_lshl_add_u32 %[t], %[t], 16, v91\n\t" \
-    "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t"
+    "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t" SNK_PADB
 // candidate window address: v104 = arena byte offset, v103 = position whose low 2 bits give the phase
 #define SNK_STEADY_ADDR_DUAL \
     "v_sub_u32_e32 v100, %[t], %[sx]\n\t" \
@@ -300,7 +334,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
-    "global_load_dword v108, %[nxoff], %[arena]\n\t" \
+    "global_load_dword v108, %[nxoff], %[arena]\n\t" SNK_PADC \
     "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t" \
     "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm]\n\t" \
     "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t" \
@@ -317,7 +351,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
 // compare, next cursor, next window + LUT reads, accounting, exit test (LIM = limit register)
 #define SNK_STEADY_REST(LIM) \
-    "s_waitcnt vmcnt(1)\n\t" \
+    "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
     "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
@@ -340,7 +374,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "ds_read_u16 %[s1], v117\n\t" \
     "v_lshrrev_b32_e32 v118, 3, %[wc]\n\t" \
     "v_and_b32_e32 v118, 0x7fe, v118\n\t" \
-    "ds_read_u16 %[ns2], v118\n\t" \
+    "ds_read_u16 %[ns2], v118\n\t" SNK_PADE \
     "v_ffbh_u32_e32 v120, v120\n\t" \
     "v_lshrrev_b32_e32 v120, 1, v120\n\t" \
     "v_min3_u32 v120, v120, %[lit], v111\n\t" \
@@ -364,7 +398,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
-      "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126"
+      "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
 // A lane may run the steady loop when its next probe is an ordinary one: inside an open block
 // that has not bailed out, search step 1, literal run and output budget far from their rare

@@ -17,7 +17,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 print(json.dumps({"group": sys.argv[2], "kernel": "snk_fast_kernel", "per_launch": tot}))
 PY
-  cat "$OUT/pmc_$g.json"; tail -1 "$OUT/run_$g.log"
+  cat "$OUT/pmc_$g.json"; tail -1 "$OUT/run_$g.log"; rm -rf "$OUT/raw_$g"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA
