@@ -18,6 +18,7 @@ import gzip
 import lzma
 import os
 import sys
+import threading
 import zlib
 from pathlib import Path
 
@@ -29,10 +30,16 @@ from .matrix import GETSIZEOF_OVERHEAD, ncd_matrix
 _EXTENSION = {"lzma": ".lzma", "gzip": ".gz", "bzip2": ".bz2", "zlib": ".ZLIB", "lz4": ".lz4"}
 
 _ctx = None
+# One device context serves every single-item call of the process, and a context is not
+# thread-safe: upload replaces the resident sequences.  The reference's own usage pattern is a
+# ThreadPoolExecutor over compressed_size (ref:snacc/cli.py:104-129), so one call's
+# upload + launch + read-back runs under this lock; calls from a pool are serialised, not corrupted.
+_ctx_lock = threading.Lock()
 
 
 def _hip_context():
-    """Process-wide device context for single-item calls (device = LOCAL_RANK or 0)."""
+    """Process-wide device context for single-item calls (device = LOCAL_RANK or 0).
+    Callers hold ``_ctx_lock``."""
     global _ctx
     if _ctx is None:
         from .hip_backend import HipContext
@@ -63,22 +70,27 @@ def compressed_size(sequences, algorithm, reverse_complement=False, save_directo
     file_ext = _EXTENSION[algorithm]          # KeyError for unknown algorithms, as in the reference
 
     if algorithm == "lz4":
-        ctx = _hip_context()
-        ctx.upload([bytes(p, encoding="utf-8") for p in parts])
         item = (0, 1) if len(parts) == 2 else (0, -1)
+        with _ctx_lock:
+            ctx = _hip_context()
+            ctx.upload([bytes(p, encoding="utf-8") for p in parts])
+            if save_directory:
+                # the frame itself, emitted on the GPU (bytes equal liblz4's)
+                compressed_seq = ctx.frames([item])[0]
+            else:
+                n = int(ctx.pairs_list([item])[0]) if len(parts) == 2 else int(ctx.singles()[0])
         if save_directory:
-            # the frame itself, emitted on the GPU (bytes equal liblz4's)
-            compressed_seq = ctx.frames([item])[0]
             _save_blob(sequences, save_directory, file_ext, compressed_seq)
             return (sequences, sys.getsizeof(compressed_seq))
-        n = int(ctx.pairs_list([item])[0]) if len(parts) == 2 else int(ctx.singles()[0])
         return (sequences, n + GETSIZEOF_OVERHEAD)
 
     if algorithm in ("gzip", "zlib") and not save_directory and os.environ.get("SNACC_DEFLATE", "hip") != "stdlib":
-        ctx = _hip_context()
-        ctx.upload([bytes(p, encoding="utf-8") for p in parts])
         item = (0, 1) if len(parts) == 2 else (0, -1)
-        return (sequences, int(ctx.deflate_pairs_list(algorithm, [item])[0]) + GETSIZEOF_OVERHEAD)
+        with _ctx_lock:
+            ctx = _hip_context()
+            ctx.upload([bytes(p, encoding="utf-8") for p in parts])
+            n = int(ctx.deflate_pairs_list(algorithm, [item])[0])
+        return (sequences, n + GETSIZEOF_OVERHEAD)
 
     sequence = bytes("".join(parts), encoding="utf-8")
     if algorithm == "lzma":

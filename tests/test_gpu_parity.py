@@ -291,6 +291,30 @@ def test_python_api_single_items(hip, golden):
         p.unlink()
 
 
+def test_python_api_from_a_thread_pool(hip, oracle_mod, tmp_path):
+    """The reference's callers run compressed_size from a ThreadPoolExecutor (ref:snacc/cli.py:104-129):
+    8 threads on the shared device context must each get the sizes of THEIR sequences."""
+    import concurrent.futures
+    from conftest import write_fasta
+    from snacc_amd import compressed_size
+    seqs, files = [], []
+    for k in range(8):
+        sq = bytes(oracle_mod.lcg_genome(70 + k, 30000 + 9000 * k))
+        f = tmp_path / f"t{k}.fa"
+        write_fasta(f, [("r", sq.decode())])
+        seqs.append(sq)
+        files.append(f)
+    keys = [f for f in files] + [(files[i], files[(3 * i + 1) % 8]) for i in range(8)] * 2
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        got = dict(ex.map(lambda k: compressed_size(k, "lz4"), keys))
+    for k in keys:
+        if type(k) == tuple:
+            exp = oracle_mod.lz4f_size_pair(seqs[files.index(k[0])], seqs[files.index(k[1])])
+        else:
+            exp = oracle_mod.lz4f_size(seqs[files.index(k)])
+        assert got[k] == exp + 33, k
+
+
 @pytest.mark.parametrize("set_name", ["acgt_small", "ragged_blocks"])
 @pytest.mark.parametrize("rc", [False, True])
 def test_cli_lz4_csv_equals_reference_cli(hip, golden, oracle_mod, tmp_path, monkeypatch, set_name, rc):
