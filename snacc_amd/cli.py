@@ -215,9 +215,14 @@ def threadpool_matrix(files, compression, num_threads, save_compression, reverse
 @click.option("-r", "--reverse_complement", is_flag=True, default=False,
               help="Whether to use the reverse complement of the sequence.")
 @click.option("--log/--no-log", "log", default=True, help="Whether to save a log.")
+@click.option("--lz4-content-size/--no-lz4-content-size", "lz4ContentSize", default=None,
+              help="(not in the reference) lz4 frames carry the 8-byte content-size field, as a py-lz4framed build "
+                   "that sets it would produce; default: the SNACC_LZ4_CONTENT_SIZE environment variable, else off.")
 def cli(sequences, fasta, directories, numThreads, compression, showProgress, saveCompression, output,
-        reverse_complement, log):
+        reverse_complement, log, lz4ContentSize=None):
     start_time = datetime.now()
+    if lz4ContentSize is not None:          # read by HipContext when it is created
+        os.environ["SNACC_LZ4_CONTENT_SIZE"] = "1" if lz4ContentSize else "0"
 
     if fasta or directories:
         click.secho("Warning: the -f and -d flags are deprecated and will be removed before release. "

@@ -782,7 +782,6 @@ int snk_frames_list(snk_ctx *c, int n_items, const int32_t *ij, const uint64_t *
 {
     if (!c || n_items < 0 || (n_items && (!ij || !offsets || !out))) return fail(c, SNK_E_ARG, "bad arguments");
     if (!c->singles_done) return fail(c, SNK_E_STATE, "snk_upload has not completed");
-    if (c->header_bytes != 7) return fail(c, SNK_E_STATE, "frame emission does not support the content_size option");
     if (!n_items) return SNK_OK;
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<SnkEmitJob> jobs((size_t)n_items);

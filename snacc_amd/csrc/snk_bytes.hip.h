@@ -483,7 +483,7 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.spos = T.snap_pos[job.xi];
     L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;
     if (!ONESHOT && job.snap == 0 && L.spos != 0u) { L.pos = L.spos; L.total = T.snap_out[job.xi]; }
-    else                                           { L.pos = 0u;     L.total = T.header_bytes; }
+    else                                           { L.pos = 0u;     L.total = L.n ? T.header_bytes : 7u; }   // empty frame: no content-size field
     if (ONESHOT) L.snap = 0;
     L.blocks_left = (L.n >> 16) + 4u;
     L.iend = 0; L.blen = 0; L.first = true; L.in_block = false;

@@ -91,6 +91,20 @@ __device__ __forceinline__ uint32_t snk_emit_block(const SnkGenSrc &s, uint32_t 
     return (uint32_t)(op - dst);
 }
 
+// XXH32 (seed 0) of fewer than 16 bytes: the frame descriptor checksum of the LZ4 frame format.
+__device__ __forceinline__ uint32_t snk_xxh32_short(const uint8_t *p, uint32_t len)
+{
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    uint32_t h = P5 + len, i = 0;
+    for (; i + 4u <= len; i += 4u) {
+        const uint32_t w = (uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16) | ((uint32_t)p[i + 3] << 24);
+        h += w * P3; h = ((h << 17) | (h >> 15)) * P4;
+    }
+    for (; i < len; ++i) { h += p[i] * P5; h = ((h << 11) | (h >> 21)) * P1; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
 __device__ __forceinline__ void snk_emit_chain(const SnkTables &T, const SnkEmitJob job, uint32_t *tbl,
                                                uint8_t *frames, uint32_t *sizes, uint32_t idx, uint32_t *status)
 {
@@ -104,10 +118,15 @@ __device__ __forceinline__ void snk_emit_chain(const SnkTables &T, const SnkEmit
     uint64_t guard = 2ull * n + 4096ull;
     uint8_t *op = frames + job.off;
     const bool linked = n > SNK_BLOCK;
-    // header: magic, FLG (version 01, block-independence bit for a single block), BD (64 KiB), HC
+    // header: magic, FLG (version 01, block-independence bit for a single block, content-size bit),
+    // BD (64 KiB), [content size, 8 bytes LE], HC = second byte of XXH32(FLG .. before HC, seed 0)
     op[0] = 0x04; op[1] = 0x22; op[2] = 0x4D; op[3] = 0x18;
-    op[4] = linked ? 0x40 : 0x60; op[5] = 0x40; op[6] = linked ? 0xC0 : 0x82;
-    op += 7;
+    const bool csize = T.header_bytes == 15u && n != 0u;      // liblz4 drops the field when the content is empty
+    op[4] = (uint8_t)((linked ? 0x40 : 0x60) | (csize ? 0x08 : 0x00)); op[5] = 0x40;
+    uint32_t hl = 2u;
+    if (csize) { for (uint32_t k = 0; k < 8u; ++k) op[6u + k] = k < 4u ? (uint8_t)(n >> (8u * k)) : 0u; hl = 10u; }
+    op[4u + hl] = (uint8_t)(snk_xxh32_short(op + 4, hl) >> 8);
+    op += 5u + hl;
     uint32_t pos = 0;
     while (pos < n) {
         const uint32_t blen = n - pos < SNK_BLOCK ? n - pos : SNK_BLOCK;

@@ -131,7 +131,7 @@ __device__ __forceinline__ void snk_gen_chain(const SnkTables &T, const SnkJob j
     s.lx = lx;
     uint64_t guard = 2ull * n + 4096ull;
 
-    if (n == 0u) { out[job.out_idx] = T.header_bytes + 4u; return; }
+    if (n == 0u) { out[job.out_idx] = 7u + 4u; return; }        // liblz4 drops the content-size field of an empty frame
     if (n <= SNK_BLOCK) {                         // one independent block, one-shot compressor
         uint32_t payload = snk_gen_block<false>(s, tbl, 0u, n, guard, status);
         out[job.out_idx] = T.header_bytes + 4u + payload + 4u;

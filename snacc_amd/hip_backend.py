@@ -184,6 +184,12 @@ class HipContext:
         self._h = h
         self.device = int(device)
         self.n = 0
+        # SNACC_LZ4_CONTENT_SIZE=1: LZ4 frames carry the 8-byte content-size field (every lz4 size
+        # grows by 8, emitted frames get the field).  liblz4's NULL-preferences frame (the default)
+        # has none; whether a given py-lz4framed wheel sets it is not knowable offline.
+        if os.environ.get("SNACC_LZ4_CONTENT_SIZE", "0") not in ("", "0"):
+            options = dict(content_size=1, **{k: v for k, v in options.items() if k != "content_size"}) \
+                if "content_size" not in options else options
         for k, v in options.items():
             self.set_option(k, v)
 

@@ -498,6 +498,62 @@ def test_emitted_frames_bytes_and_roundtrip(hip, golden, oracle_mod, tmp_path):
             assert f == liblz4_ref.compress_frame(data), (i, j)
 
 
+def test_emitted_frames_equal_liblz4_by_hash(hip):
+    """Frame BYTES pinned on any box: sha256 + length of what `snk_frames_list` emits against the
+    hashes of the liblz4 1.9.3 binary's frames for the same generator-defined inputs
+    (tests/golden/frame_hashes.json, made by tests/golden/make_frame_hashes.py) -- with the
+    NULL-preferences header and with the content-size field (option content_size /
+    SNACC_LZ4_CONTENT_SIZE=1).  ref:snacc/pairwise_ncd.py:80-88."""
+    import hashlib
+    import json
+    from pathlib import Path
+    from frame_items import ITEMS, build_sequences
+    gold = json.loads((Path(__file__).parent / "golden" / "frame_hashes.json").read_text())
+    seqs = build_sequences()
+    assert [tuple(f["item"]) for f in gold["frames"]] == ITEMS
+    for cs in (0, 1):
+        with hip.HipContext(0, content_size=cs) as ctx:
+            ctx.upload(seqs)
+            frames = ctx.frames(ITEMS)
+            singles, pairs = ctx.singles(), ctx.pairs()
+        for f, g in zip(frames, gold["frames"]):
+            i, j = g["item"]
+            assert len(f) == (g["len_content_size"] if cs else g["len"]), (cs, i, j)
+            assert hashlib.sha256(f).hexdigest() == (g["sha256_content_size"] if cs else g["sha256"]), (cs, i, j)
+            assert len(f) == (int(singles[i]) if j < 0 else int(pairs[i, j])), (cs, i, j)      # the size kernels agree
+
+
+def test_content_size_from_environment_and_cli(hip, oracle_mod, tmp_path, monkeypatch):
+    """SNACC_LZ4_CONTENT_SIZE=1 / --lz4-content-size: every lz4 size grows by 8 (non-empty input)."""
+    from click.testing import CliRunner
+    from conftest import write_fasta
+    from snacc_amd import cli as cli_mod
+    seqs = [bytes(oracle_mod.lcg_genome(81 + k, 20000 + 30000 * k)) for k in range(3)]
+    monkeypatch.setenv("SNACC_LZ4_CONTENT_SIZE", "1")
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        s1, p1 = ctx.singles(), ctx.pairs()
+    monkeypatch.setenv("SNACC_LZ4_CONTENT_SIZE", "0")
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        s0, p0 = ctx.singles(), ctx.pairs()
+    assert np.array_equal(s1, s0 + 8) and np.array_equal(p1, p0 + 8)
+    d = tmp_path / "fa"
+    d.mkdir()
+    for k, sq in enumerate(seqs):
+        write_fasta(d / f"g{k}.fasta", [("r", sq.decode())])
+    monkeypatch.chdir(tmp_path)
+    outs = []
+    for flag in ("--no-lz4-content-size", "--lz4-content-size"):
+        out = tmp_path / (flag.strip("-") + ".csv")
+        res = CliRunner().invoke(cli_mod.cli, [str(d), "-o", str(out), "-c", "lz4", "--no-show-progress", "--no-log", flag])
+        assert res.exit_code == 0, res.output
+        outs.append(np.loadtxt(out, delimiter=",", skiprows=1, usecols=(1, 2, 3)))
+    from snacc_amd.matrix import ncd_matrix
+    for m, (s, p) in zip(outs, ((s0, p0), (s1, p1))):
+        assert np.array_equal(m, ncd_matrix(s.astype(np.int64) + 33, p.astype(np.int64) + 33))
+
+
 def test_save_compression_lz4_cli_and_api(hip, oracle_mod, tmp_path, monkeypatch):
     """`-s` with `-c lz4`: one .lz4 blob per file and per ordered pair, named as the reference names
     them, each a valid frame of the right content; compressed_size(..., save_directory=...) likewise."""
