@@ -7,8 +7,9 @@ skipped, each sequence line is ``rstrip()``-ed and joined, then spaces and ``\\r
 are removed.  Reverse complement follows ``Bio.Seq``: IUPAC ambiguous DNA table,
 case preserved, unknown characters unchanged; a sequence with ``U`` and no ``T``
 is complemented as RNA; ``T`` and ``U`` together raise ``ValueError``.
-(Biopython itself is absent from this image, so this restatement is checked
-against hand-written cases only -- see tests/test_fasta.py.)
+(Biopython itself is absent from this image, so this restatement is checked against the
+reference's own fixture and against cases worked out by hand from Biopython's documented
+reader -- tests/test_fasta_native.py::test_documented_reader_rules, tests/test_host_logic.py.)
 """
 from pathlib import Path
 

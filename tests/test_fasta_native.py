@@ -125,3 +125,45 @@ def test_extract_many_threads(tmp_path, oracle_mod):
     assert L.snk_fasta_extract_many(2, arr2, 0, 2, outs2, lens2) == hip_backend.E_EMPTY
     assert outs2[0] is None and outs2[1] is None
     assert b"bad.fa" in L.snk_fasta_last_error()
+
+
+# Cases worked out BY HAND from the documented behaviour of Biopython's plain FASTA reader
+# (Bio.SeqIO.FastaIO.SimpleFastaParser, the reader behind SeqIO.parse(path, "fasta") at
+# ref:snacc/pairwise_ncd.py:32) and of Seq.reverse_complement (ref:snacc/pairwise_ncd.py:34).
+# Each row: (rule, file text, concatenated sequence, the same with -r).
+DOCUMENTED_RULES = [
+    ("blank lines inside a record are dropped: every line is rstrip()-ed before joining",
+     ">a\nAC\n\n\nGT\n", "ACGT", "ACGT"),
+    ("a header is a line whose FIRST character is '>': after leading blanks it is sequence text, "
+     "and spaces are removed from the joined sequence",
+     ">a\nAC\n >b\nGT\n", "AC>bGT", "ACv>GT"),          # lower-case b is the IUPAC code B: complement v
+    ("text before the first '>' line (comments, stray residues) is skipped",
+     "# produced by tool X\nACGTACGT\n\n>a\nTTG\n", "TTG", "CAA"),
+    ("no validation of residues: digits, '*' and '-' stay, and the complement leaves them unchanged",
+     ">a\nAC12*-GT\n", "AC12*-GT", "AC-*21GT"),
+    ("text mode with universal newlines: a lone '\\r' ends a line",
+     ">a\rAC\rGT\r>b\rTT\r", "ACGTTT", "ACGTAA"),
+    ("only trailing white space is stripped and only spaces are removed: an inner tab stays",
+     ">a\nAC\tGT \n", "AC\tGT", "AC\tGT"),
+    ("a record may be empty; the file still yields the residues of the others",
+     ">a\n>b\nAC\n>c\n", "AC", "GT"),
+    ("-r reverse-complements every record on its own, records stay in file order "
+     "(ref:snacc/pairwise_ncd.py:33-36)",
+     ">a\nAAC\n>b\nGGT\n", "AACGGT", "GTTACC"),
+    ("case is preserved, also by the complement", ">a\nacgtN\n", "acgtN", "Nacgt"),
+    ("IUPAC ambiguity codes complement as M<->K R<->Y V<->B H<->D, W S N fixed",
+     ">a\nMRWSYKVHDBN\n", "MRWSYKVHDBN", "NVHDBMRSWYK"),
+    ("the title line is not sequence, whatever it contains", ">ACGT ACGT>>\nTG\n", "TG", "CA"),
+    ("CRLF files: the reference's own fixture style", ">a\r\nAC\r\nGT\r\n", "ACGT", "ACGT"),
+]
+
+
+@pytest.mark.parametrize("rule,text,seq,seq_rc", DOCUMENTED_RULES, ids=[r[0][:40] for r in DOCUMENTED_RULES])
+def test_documented_reader_rules(tmp_path, rule, text, seq, seq_rc):
+    p = tmp_path / "case.fa"
+    with open(p, "w", newline="") as f:
+        f.write(text)
+    assert fasta.read_sequence(p, False) == seq, rule
+    assert fasta.read_sequence(p, True) == seq_rc, rule
+    assert hip_backend.fasta_extract(p, False) == seq.encode(), rule
+    assert hip_backend.fasta_extract(p, True) == seq_rc.encode(), rule
