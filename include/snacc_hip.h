@@ -129,6 +129,12 @@ int snk_sync(snk_ctx *ctx, void *hip_stream);
  * snk_pairs_device it is valid after snk_sync().  Returns < 0 if unavailable. */
 double snk_last_pairs_ms(snk_ctx *ctx);
 
+/* Device times (ms) of every snk_pairs_device / snk_pairs_list launch since the previous call
+ * of this function, oldest first: up to `cap` values into ms[], returns how many launches were
+ * logged (bench.py averages them over its timed steps), or a negative error code -- SNK_E_STATE
+ * when a logged launch has not completed yet (call snk_sync first).  Clears the log. */
+int snk_pairs_ms_log(snk_ctx *ctx, double *ms, int cap);
+
 /* ---- FASTA ingest on the host ------------------------------------------
  * Replaces extract_sequences (ref:snacc/pairwise_ncd.py:15-39: Bio.SeqIO.parse + per-record
  * reverse_complement + concatenation) for the batched path: every file is parsed once, by

@@ -21,9 +21,18 @@ thread_local std::string g_create_error;
 struct snk_ctx_impl {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;      // event pair of the last launch (owned by ev_log)
     bool ev_valid = false;
     double ms_accum = -1.0;          // sum over the tiles of the last snk_pairs call
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_log;   // one pair per pair launch since the last snk_pairs_ms_log
+    size_t ev_used = 0;
+    int n_cus = 0;                   // compute units of the device: size of a persistent launch
+    uint32_t *d_yorder = nullptr;    // sequence indices by decreasing length (column order of ragged dense tiles)
+    uint32_t *d_queue = nullptr;     // ring of batch counters for launches with the dynamic schedule
+    unsigned queue_next = 0;
+    int fast_dynamic = -1;           // -1 auto (by length spread), 0 static round robin, 1 atomic queue
+    bool dense_tile = false;         // the last build_jobs found every pair of the tile fit for the 2-bit kernel
+    hipEvent_t jobs_busy = nullptr;  // last launch that reads d_jobs: waited for before the list is rewritten
     std::string err;
 
     // options
@@ -44,6 +53,7 @@ struct snk_ctx_impl {
 
     // resident sequences
     int n = 0, n_packed = 0;
+    uint32_t min_len = 0, max_len = 0;
     std::vector<uint32_t> len;
     std::vector<uint32_t> boff;      // byte offset of every sequence in d_bytes
     std::vector<uint8_t> is_packed;
@@ -60,7 +70,7 @@ struct snk_ctx_impl {
     bool singles_done = false;
 
     // scratch for pair launches (grown on demand)
-    SnkJob *d_jobs = nullptr; size_t jobs_cap = 0;
+    SnkJob *d_jobs = nullptr; size_t jobs_cap = 0; bool jobs_in_flight = false;
     uint32_t *d_out = nullptr; size_t out_cap = 0;
     std::vector<SnkJob> h_jobs;
 };
@@ -89,7 +99,7 @@ template <typename T> void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p =
 void free_sequences(snk_ctx_impl *c)
 {
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
-    dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast);
+    dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
     dfree(c->d_snap_gen); dfree(c->d_single);
     c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
     if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
@@ -148,8 +158,11 @@ int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
 }
 
 // Launch the kernels over a job list laid out as [2-bit jobs | linked byte jobs | one-shot jobs].
+// tile: when non-NULL and its rows > 0, the 2-bit jobs are the dense tile (no list on the device).
+struct SnkTileDesc { uint32_t r0 = 0, rows = 0, n = 0; bool ragged = false; };
+
 int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_fast, size_t n_bytes, size_t n_gen,
-                uint32_t *d_out, bool singles = false)
+                uint32_t *d_out, bool singles = false, const SnkTileDesc *tile = nullptr)
 {
     SnkTables T = make_tables(c);
     if (n_fast) {
@@ -158,6 +171,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", chains);
+        SnkFastGrid G;
+        const bool dense = tile && tile->rows > 0;
+        G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
+        G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
+        G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
         const void *fk = singles ? (const void *)snk_fast_singles_kernel
                                  : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel;
         HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -167,16 +185,21 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             if (fa.sharedSizeBytes != 0)
                 return fail(c, SNK_E_STATE, "snk_fast_kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
         }
-        const uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
+        // persistent launch: one workgroup per compute unit at most (the LDS admits one), waves walk the batches
+        uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
+        if (c->n_cus > 0 && grid > (uint32_t)c->n_cus) grid = (uint32_t)c->n_cus;
+        const bool dynamic = c->fast_dynamic < 0 ? (singles || (tile && tile->ragged)) : c->fast_dynamic != 0;
+        if (dynamic) {       // ragged lengths: later batches come from an atomic counter that starts behind the waves' first ones
+            if (dense) G.yorder = c->d_yorder;               // ... and the longest suffixes go out first
+            G.queue = c->d_queue + (c->queue_next++ & 63u);
+            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.queue, (int)(grid * waves), 1, st));
+        }
         if (singles)
-            hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                               T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (c->fast_asm)
-            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                               T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else
-            hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                               T, d_jobs, (uint32_t)n_fast, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
     if (n_bytes && c->compact_ok) {
@@ -293,21 +316,43 @@ int build_jobs(snk_ctx_impl *c, size_t n_pairs, PairAt pair_at, size_t &n_fast, 
         else gen.push_back(jb);
     }
     n_fast = fast.size(); n_bytes = bytes.size(); n_gen = gen.size();
+    c->dense_tile = n_fast == n_pairs;
     c->h_jobs.swap(fast);
     c->h_jobs.insert(c->h_jobs.end(), bytes.begin(), bytes.end());
     c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
     return SNK_OK;
 }
 
-int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_bytes, size_t n_gen, uint32_t *d_out)
+// One launch over the job list in c->h_jobs (or over a dense tile: nothing is copied then).  Every launch gets
+// its own hipEvent pair (snk_last_pairs_ms, snk_pairs_ms_log).  The device copy of the list is ONE buffer per
+// context: a launch that needs it waits (on the host) for the previous launch that read it, on whatever stream
+// that one ran, so interleaved calls on two streams stay correct; dense tiles share nothing.
+int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_bytes, size_t n_gen, uint32_t *d_out,
+              const SnkTileDesc *tile = nullptr)
 {
     const size_t nj = n_fast + n_bytes + n_gen;
     if (nj == 0) return SNK_OK;
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), nj * sizeof(SnkJob), hipMemcpyHostToDevice, st));
+    const bool dense = tile && tile->rows > 0;
+    if (!dense) {
+        if (c->jobs_in_flight) { HIPCHK(c, hipEventSynchronize(c->jobs_busy)); c->jobs_in_flight = false; }
+        HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), nj * sizeof(SnkJob), hipMemcpyHostToDevice, st));
+    }
+    if (c->ev_used == c->ev_log.size()) {
+        if (c->ev_log.size() < 4096) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIPCHK(c, hipEventCreate(&a));
+            HIPCHK(c, hipEventCreate(&b));
+            c->ev_log.emplace_back(a, b);
+        } else {
+            c->ev_used = c->ev_log.size() - 1;      // log full: the last slot is reused (snk_pairs_ms_log reports what it has)
+        }
+    }
+    c->ev0 = c->ev_log[c->ev_used].first; c->ev1 = c->ev_log[c->ev_used].second; c->ev_used++;
     HIPCHK(c, hipEventRecord(c->ev0, st));
-    int rc = launch_jobs(c, st, c->d_jobs, n_fast, n_bytes, n_gen, d_out);
+    int rc = launch_jobs(c, st, c->d_jobs, n_fast, n_bytes, n_gen, d_out, false, tile);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, st));
+    if (!dense) { HIPCHK(c, hipEventRecord(c->jobs_busy, st)); c->jobs_in_flight = true; }
     c->ev_valid = true;
     c->ms_accum = -1.0;
     return SNK_OK;
@@ -368,8 +413,14 @@ int snk_ctx_create(int device, snk_ctx **out)
     } while (0)
     CRCHK(hipSetDevice(device));
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CRCHK(hipEventCreate(&c->ev0));
-    CRCHK(hipEventCreate(&c->ev1));
+    CRCHK(hipEventCreate(&c->jobs_busy));
+    {
+        hipDeviceProp_t prop;
+        CRCHK(hipGetDeviceProperties(&prop, device));
+        c->n_cus = prop.multiProcessorCount;
+    }
+    CRCHK(hipMalloc((void **)&c->d_queue, 64 * sizeof(uint32_t)));
+    CRCHK(hipMemset(c->d_queue, 0, 64 * sizeof(uint32_t)));
     CRCHK(hipMalloc((void **)&c->d_status, sizeof(uint32_t)));
     CRCHK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
     CRCHK(hipMalloc((void **)&c->d_zero, 4 * SNK_PAD));
@@ -402,8 +453,9 @@ void snk_ctx_destroy(snk_ctx *c)
     free_sequences(c);
     dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_lut_h2c4); dfree(c->d_hashset); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &e : c->ev_log) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->jobs_busy) (void)hipEventDestroy(c->jobs_busy);
+    dfree(c->d_queue);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -420,6 +472,9 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         c->fast_waves = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
+    } else if (k == "fast_dynamic") {
+        if (value < -1 || value > 1) return fail(c, SNK_E_ARG, "fast_dynamic must be -1 (auto), 0 or 1");
+        c->fast_dynamic = (int)value;
     } else if (k == "gen_chains") {
         if (value < 1 || value > 9) return fail(c, SNK_E_ARG, "gen_chains must be 1..9");
         c->gen_chains = (int)value;
@@ -475,6 +530,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     if (!c || n_seq < 0 || (n_seq > 0 && (!seqs || !lens))) return fail(c, SNK_E_ARG, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->jobs_in_flight) { HIPCHK(c, hipEventSynchronize(c->jobs_busy)); c->jobs_in_flight = false; }
     free_sequences(c);
     if (n_seq == 0) return SNK_OK;
 
@@ -487,7 +543,11 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         boff[g] = btot; btot += ((size_t)lens[g] + 63) / 64 * 64 + SNK_PAD;
     }
     c->len.resize(n);
-    for (size_t g = 0; g < n; ++g) c->len[g] = (uint32_t)lens[g];
+    c->min_len = 0xFFFFFFFFu; c->max_len = 0u;
+    for (size_t g = 0; g < n; ++g) {
+        c->len[g] = (uint32_t)lens[g];
+        c->min_len = std::min(c->min_len, c->len[g]); c->max_len = std::max(c->max_len, c->len[g]);
+    }
     if (btot >= 0xFFF00000ull)
         return fail(c, SNK_E_TOOBIG, "ASCII arena of %zu bytes exceeds the 4 GiB offset range", btot);
 
@@ -623,6 +683,13 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipMemcpy(c->d_bytes_off, bo.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->boff = bo;
     HIPCHK(c, hipMemcpy(c->d_len, c->len.data(), n * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> order(n);
+        for (size_t g = 0; g < n; ++g) order[g] = (uint32_t)g;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->len[a] > c->len[b]; });
+        HIPCHK(c, hipMalloc((void **)&c->d_yorder, n * 4));
+        HIPCHK(c, hipMemcpy(c->d_yorder, order.data(), n * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMemcpy(c->d_snap_pos, spos.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->d_snap_out, 0, n * 4, c->stream));
     c->n = n_seq;
@@ -683,15 +750,26 @@ int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream
     const size_t N = (size_t)c->n, np = (size_t)(r1 - r0) * N;
     if (!np) return SNK_OK;
     size_t nf = 0, nb = 0, ng = 0;
-    // order: suffix j outer, prefix i inner => the chains of a workgroup share seq_j
-    int rc = build_jobs(c, np, [&](size_t t, int &i, int &j, uint32_t &o) {
-        j = (int)(t / (size_t)(r1 - r0)); i = r0 + (int)(t % (size_t)(r1 - r0));
-        o = (uint32_t)((size_t)(i - r0) * N + (size_t)j);
-    }, nf, nb, ng);
+    int rc = SNK_OK;
+    if (!c->force_generic && c->n_packed == c->n && (uint64_t)c->min_len * 2u > SNK_BLOCK && (uint64_t)c->max_len * 2u < 0x7E000000ull) {
+        nf = np; c->dense_tile = true;             // every pair fits the 2-bit kernel: no job list at all
+    } else {
+        // order: suffix j outer, prefix i inner => the chains of a wave share seq_j
+        rc = build_jobs(c, np, [&](size_t t, int &i, int &j, uint32_t &o) {
+            j = (int)(t / (size_t)(r1 - r0)); i = r0 + (int)(t % (size_t)(r1 - r0));
+            o = (uint32_t)((size_t)(i - r0) * N + (size_t)j);
+        }, nf, nb, ng);
+        if (rc) return rc;
+    }
+    SnkTileDesc tile;
+    if (c->dense_tile) {      // every pair goes to the 2-bit kernel: the kernel derives the pair from the job number
+        tile.r0 = (uint32_t)r0; tile.rows = (uint32_t)(r1 - r0); tile.n = (uint32_t)N;
+    }
+    // ragged lengths (a job costs ~ tail of x + len y): hand batches out dynamically
+    tile.ragged = (uint64_t)c->max_len * 10u > (uint64_t)c->min_len * 11u;
+    rc = ensure_scratch(c, tile.rows ? 0 : np, 0);
     if (rc) return rc;
-    rc = ensure_scratch(c, np, 0);
-    if (rc) return rc;
-    return run_pairs(c, st, nf, nb, ng, (uint32_t *)d_sizes);
+    return run_pairs(c, st, nf, nb, ng, (uint32_t *)d_sizes, &tile);
 }
 
 int snk_sync(snk_ctx *c, void *hip_stream)
@@ -711,8 +789,10 @@ int snk_pairs(snk_ctx *c, int r0, int r1, uint32_t *sizes)
     // however large N is; a tile still holds whole rows so one workgroup's chains share a suffix.
     const size_t N = (size_t)c->n;
     const size_t max_pairs = (size_t)4 << 20;
-    int tile_rows = (int)std::max<size_t>(1, std::min<size_t>((size_t)(r1 - r0), max_pairs / N));
-    if (tile_rows >= 84) tile_rows = tile_rows / 84 * 84;          // multiples of the chains per workgroup
+    // equal tiles (no small last one: a tile that does not fill the card costs as much as one that does)
+    const size_t max_rows = std::max<size_t>(1, max_pairs / N);
+    const size_t n_tiles = ((size_t)(r1 - r0) + max_rows - 1) / max_rows;
+    const int tile_rows = (int)(((size_t)(r1 - r0) + n_tiles - 1) / n_tiles);
     double ms_total = 0.0;
     for (int t0 = r0; t0 < r1; t0 += tile_rows) {
         const int t1 = std::min(r1, t0 + tile_rows);
@@ -820,6 +900,24 @@ int snk_frames_list(snk_ctx *c, int n_items, const int32_t *ij, const uint64_t *
 #undef EMCHK
     cleanup();
     return check_status(c);
+}
+
+int snk_pairs_ms_log(snk_ctx *c, double *ms, int cap)
+{
+    if (!c || cap < 0 || (cap && !ms)) return SNK_E_ARG;
+    const size_t n = c->ev_used;
+    int k = 0;
+    for (size_t t = 0; t < n; ++t) {
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, c->ev_log[t].first, c->ev_log[t].second) != hipSuccess) {
+            c->ev_used = 0; c->ev_valid = false;
+            return fail(c, SNK_E_STATE, "a logged launch has not completed (call snk_sync first)");
+        }
+        if (k < cap) ms[k] = (double)v;
+        k++;
+    }
+    c->ev_used = 0; c->ev_valid = false;
+    return k;
 }
 
 double snk_last_pairs_ms(snk_ctx *c)

@@ -433,10 +433,9 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 // ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
 template <bool ASM>
-__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off)
+__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off)
 {
-    SnkWin &w = L.w;
-    snk_g8 *const arena = L.s.arena;
+    SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
 #ifdef SNK_HOST_EMU
     const uint16_t *const lut0 = slot;
 #else
@@ -547,16 +546,38 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, uint16_t *tbl, u
     snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
 }
 
-// One chain of the 2-bit kernel.  `lds` = this chain's 1904 bytes, `slot` = the
-// workgroup's 5-mer -> slot LUT.
-template <bool ASM>
-__device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob job,
-                                               uint8_t *lds, uint32_t lds_off, const uint16_t *slot,
-                                               uint32_t *out, uint32_t *status)
+// How job numbers map to ordered pairs, and how the waves of a launch share them.
+//   jobs != NULL : explicit list (mixed tiles, pair lists, the single-sequence pass).
+//   jobs == NULL : dense tile of the N x N matrix: job q is the pair (x = r0 + q % rows, y = q / rows),
+//                  its size goes to out[(x - r0) * n + y].  Suffix-major, so consecutive jobs share y.
+// Work is handed out per WAVE in batches of `batch` consecutive jobs (= the lanes of a wave): wave w of
+// the launch starts with batch w; its later batches are w + k * (waves of the launch) when `queue` is
+// NULL (uniform lengths: the waves of a workgroup keep walking the same suffix y, the L1 stays hot), or
+// come from the atomic counter *queue (ragged lengths: no wave idles while jobs are left).  Inside a
+// wave a lane that finishes its pair takes the next job of the wave's batch at once.
+struct SnkFastGrid {
+    const SnkJob *jobs;
+    uint32_t n_jobs;
+    uint32_t r0, rows, n;
+    uint32_t batch;
+    uint32_t *queue;          // starts at (waves of the launch); NULL = static round robin
+    const uint32_t *yorder;   // dense tile: column visited k-th (longest suffix first when lengths are ragged: the
+                              // big jobs go out first and the launch ends on small ones); NULL = column k
+};
+
+__device__ __forceinline__ SnkJob snk_fast_job(const SnkFastGrid &G, uint32_t q)
 {
-    uint16_t *tbl = (uint16_t *)lds;
-    uint32_t *bm = (uint32_t *)(lds + SNK_FSLOTS * 2u);
-    SnkFastLane L;
+    if (G.jobs) return G.jobs[q];
+    SnkJob jb;
+    const uint32_t yk = q / G.rows, xr = q - yk * G.rows;
+    const uint32_t yi = G.yorder ? G.yorder[yk] : yk;
+    jb.xi = (int32_t)(G.r0 + xr); jb.yi = (int32_t)yi; jb.out_idx = xr * G.n + yi; jb.snap = 0;
+    return jb;
+}
+
+// Lane state at the start of a job (the table in LDS is initialised by snk_fast_kernel_body).
+__device__ __forceinline__ void snk_fast_lane_init(SnkFastLane &L, const SnkTables &T, const SnkJob job)
+{
     const uint32_t lx = T.len[job.xi];
     const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
     L.s.arena = (snk_g8 *)T.packed_arena;
@@ -575,27 +596,14 @@ __device__ __forceinline__ void snk_fast_chain(const SnkTables &T, const SnkJob 
     L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos - L.k3; L.endcode = 0;     // mfl1 = 0: first iteration opens a block
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0x80000000u; L.w.lim = 0u; L.w.r0 = L.w.r1 = L.w.nx = 0u;
-
-    for (;;) {
-        // ---- head: general probes and reservoir re-seats until every lane of the wave is eligible ----
-        for (;;) {
-            bool ok = snk_fast_eligible(L);
-            if (!ok && L.cur + L.step <= L.mfl1) {           // inside a block: can the reservoir be re-seated?
-                const uint32_t cur = L.cur;
-                if (cur >= lx + 4u)                        snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
-                else if (cur >= 4u && cur + 12u <= lx)     snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
-                ok = snk_fast_eligible(L);
-            }
-            if (__builtin_expect(!__any(!ok), 1)) break;
-            if (!ok && snk_fast_iter(L, T, tbl, bm, slot, out, status)) return;
-        }
-        snk_fast_steady<ASM>(L, tbl, bm, slot, lds_off);
-    }
 }
 
-// grid: one workgroup per `lanes*waves` jobs.  dynamic LDS = 2 KiB LUT + 1904 B per chain.
+// Persistent workgroup: `waves` waves of `lanes` chains; dynamic LDS = 2 KiB LUT + 1904 B per chain.
+// Every wave runs ONE flat loop: hand jobs to lanes that have none, general probes until every
+// working lane is eligible, steady loop until some lane needs service.  The wave leaves when its
+// lanes are idle and no job is left.
 template <bool ASM>
-__device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
+__device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkFastGrid &G,
                                                      uint32_t lanes, uint32_t *out, uint32_t *status)
 {
 #ifndef SNK_HOST_EMU
@@ -604,74 +612,128 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     uint16_t *slot = (uint16_t *)snk_lds8;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
-    const uint32_t chains = lanes * waves;
 
     for (uint32_t t = tid; t < 512u; t += SNK_COOP(blockDim.x))
         ((uint32_t *)slot)[t] = ((const uint32_t *)T.lut_slot)[t];
-
-    // chain c of the workgroup -> lane c / waves of wave c % waves  (spreads a
-    // partially filled tail group over all waves)
-    const uint32_t c = lane * waves + wave;
-    const uint32_t j = blockIdx.x * chains + c;
-    const bool active = lane < lanes && j < n_jobs;
-    const uint32_t mine_off = SNK_FLUT_B + (wave * lanes + (lane < lanes ? lane : 0u)) * SNK_FCHAIN_B;   // LDS address: dynamic LDS starts at 0
-    uint8_t *mine = snk_lds8 + mine_off;
-
-    SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
-    if (active) job = jobs[j];
-
-    // cooperative table initialisation from the prefix snapshot (or the all-zero start state)
-    for (uint32_t l = 0; l < lanes; ++l) {
-        const int a   = __shfl((int)active, (int)l);
-        const int xi  = __shfl(job.xi, (int)l);
-        const int snp = __shfl(job.snap, (int)l);
-        if (!a) continue;
-        uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + l) * SNK_FCHAIN_B;
-        const uint32_t spos = T.snap_pos[xi];
-        const bool use = (snp == 0) && (spos != 0u);
-        const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
-        // offsets from the virtual base of the block before spos (k3 = -lx mod 4, see snk_fast_steady)
-        const uint32_t k3 = (0u - T.len[xi]) & 3u;
-        const uint32_t pvb = spos - 65536u - k3;
-        for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
-            uint32_t v = k3 * 0x10001u;                       // stream start: every slot holds position 0
-            if (use) {
-                const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
-                const uint32_t lo = (a0 != 0u && a0 + 65536u >= spos) ? a0 - pvb : 0u;   // previous block, else dead
-                const uint32_t hi = (a1 != 0u && a1 + 65536u >= spos) ? a1 - pvb : 0u;
-                v = lo | (hi << 16);
-            }
-            ((uint32_t *)dst)[t] = v;
-        }
-        // no snapshot: position 0 counts as "written in this block"
-        for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;
-    }
     __syncthreads();
 
-    if (active) snk_fast_chain<ASM>(T, job, mine, mine_off, slot, out, status);
+    const bool lane_on = lane < lanes;
+    const uint32_t mine_off = SNK_FLUT_B + (wave * lanes + (lane_on ? lane : 0u)) * SNK_FCHAIN_B;   // LDS address: dynamic LDS starts at 0
+    uint8_t *const mine = snk_lds8 + mine_off;
+    uint16_t *const tbl = (uint16_t *)mine;
+    uint32_t *const bm = (uint32_t *)(mine + SNK_FSLOTS * 2u);
+
+    const uint32_t n_batches = (G.n_jobs + G.batch - 1u) / G.batch;
+    const uint32_t wid = blockIdx.x * waves + wave, wtotal = gridDim.x * waves;
+    uint32_t bcur = wid;                         // wave-uniform: the batch the wave takes next (its first: its own number)
+    bool first = true;
+    uint32_t wb = 0u, we = 0u;                   // wave-uniform: jobs [wb, we) of the current batch not handed out yet
+    bool dry = false;                            // wave-uniform: no batch left
+    bool have = false;                           // this lane works on a pair
+    bool parked = false;                         // ... has reached its suffix y and waits for the wave's lanes still inside their x
+    SnkFastLane L;
+    L.s.lx = 0u; L.cur = 0u;
+
+    for (;;) {
+        // ---- hand jobs to the lanes that have none ----
+        bool need = lane_on && !have;
+        while (!dry && __any(need)) {
+            if (wb >= we) {
+                if (first) {
+                    first = false;
+                } else if (G.queue) {
+                    uint32_t b = 0u;
+                    if (lane == 0u) b = atomicAdd(G.queue, 1u);
+                    bcur = (uint32_t)__shfl((int)b, 0);
+                } else {
+                    bcur += wtotal;
+                }
+                if (bcur >= n_batches) { dry = true; break; }
+                wb = bcur * G.batch;
+                we = wb + G.batch < G.n_jobs ? wb + G.batch : G.n_jobs;
+            }
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            const uint32_t avail = we - wb;
+            const bool take = need && rank < avail;
+            SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
+            if (take) job = snk_fast_job(G, wb + rank);
+            // cooperative table initialisation of every taking lane: prefix snapshot, or the all-zero start state
+            for (unsigned long long tm = __builtin_amdgcn_ballot_w64(take); tm; tm &= tm - 1ull) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(tm);
+                const int xi  = __shfl(job.xi, (int)l);
+                const int snp = __shfl(job.snap, (int)l);
+                uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + l) * SNK_FCHAIN_B;
+                const uint32_t spos = T.snap_pos[xi];
+                const bool use = (snp == 0) && (spos != 0u);
+                const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
+                // offsets from the virtual base of the block before spos (k3 = -lx mod 4, see snk_fast_steady)
+                const uint32_t k3 = (0u - T.len[xi]) & 3u;
+                const uint32_t pvb = spos - 65536u - k3;
+                for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
+                    uint32_t v = k3 * 0x10001u;                       // stream start: every slot holds position 0
+                    if (use) {
+                        const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
+                        const uint32_t lo = (a0 != 0u && a0 + 65536u >= spos) ? a0 - pvb : 0u;   // previous block, else dead
+                        const uint32_t hi = (a1 != 0u && a1 + 65536u >= spos) ? a1 - pvb : 0u;
+                        v = lo | (hi << 16);
+                    }
+                    ((uint32_t *)dst)[t] = v;
+                }
+                // no snapshot: position 0 counts as "written in this block"
+                for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;
+            }
+            if (take) { snk_fast_lane_init(L, T, job); have = true; need = false; parked = false; }
+            const uint32_t asked = (uint32_t)__builtin_popcountll(mask);
+            wb += asked < avail ? asked : avail;
+        }
+        if (!__any(have)) return;
+
+        // ---- general probes and reservoir re-seats until every working lane is eligible ----
+        bool refill = false;                     // wave-uniform: a lane has finished and a job may be left for it
+        for (;;) {
+            // Lanes of a wave share their suffix y (jobs are suffix-major) but reach it after x tails of
+            // different lengths.  A lane that arrives parks until no lane of the wave is inside its x any
+            // more: the wave then walks y as one band of a few KB and the L1 keeps serving the windows.
+            const bool anyx = __any(have && L.cur < L.s.lx + 4u);      // wave-uniform: some lane is still inside its x
+            if (!anyx) parked = false;
+            bool ok = !have || parked || snk_fast_eligible(L);
+            if (!ok && L.cur + L.step <= L.mfl1) {           // inside a block: can the reservoir be re-seated?
+                const uint32_t cur = L.cur, lx = L.s.lx;
+                if (cur >= lx + 4u) {
+                    if (L.w.org != lx && anyx) parked = true;                 // first time on y
+                    snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
+                } else if (cur >= 4u && cur + 12u <= lx)   snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
+                ok = parked || snk_fast_eligible(L);
+            }
+            if (__builtin_expect(!__any(!ok), 1)) break;
+            if (!ok && snk_fast_iter(L, T, tbl, bm, slot, out, status)) have = false;        // frame complete
+            if (!dry && __any(lane_on && !have)) { refill = true; break; }
+        }
+        if (refill) continue;
+        if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
+        if (have && !parked) snk_fast_steady<ASM>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off);
+    }
 }
 
 #ifndef SNK_HOST_EMU
 // phase B: ordered pairs (the dominant kernel of the bench)
-__global__ void snk_fast_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
-                                uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void snk_fast_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body<true>(T, jobs, n_jobs, lanes, out, status);
+    snk_fast_kernel_body<true>(T, G, lanes, out, status);
 }
 
 // the same with the C++ statement of the steady loop (option fast_asm = 0: cross-check of the
 // hand-scheduled loop in the tests, A/B timing)
-__global__ void snk_fast_cxx_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
-                                    uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void snk_fast_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body<false>(T, jobs, n_jobs, lanes, out, status);
+    snk_fast_kernel_body<false>(T, G, lanes, out, status);
 }
 
 // phase A: single sequences + prefix snapshots at upload (same code, own symbol so that profiles
 // keep the two phases apart)
-__global__ void snk_fast_singles_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
-                                        uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void snk_fast_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body<true>(T, jobs, n_jobs, lanes, out, status);
+    snk_fast_kernel_body<true>(T, G, lanes, out, status);
 }
 #endif

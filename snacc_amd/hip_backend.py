@@ -21,7 +21,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
     "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
-    "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms",
+    "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms", "snk_pairs_ms_log",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
     "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_pairs_device", "snk_deflate_last_ms",
 )
@@ -105,6 +105,8 @@ def load():
     L.snk_sync.argtypes = [vp, vp]
     L.snk_last_pairs_ms.restype = ctypes.c_double
     L.snk_last_pairs_ms.argtypes = [vp]
+    L.snk_pairs_ms_log.restype = i32
+    L.snk_pairs_ms_log.argtypes = [vp, ctypes.POINTER(ctypes.c_double), i32]
     L.snk_fasta_extract.restype = i32
     L.snk_fasta_extract.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
     L.snk_fasta_extract_many.restype = i32
@@ -330,3 +332,11 @@ class HipContext:
 
     def last_pairs_ms(self):
         return float(self._L.snk_last_pairs_ms(self._h))
+
+    def pairs_ms_log(self, cap=4096):
+        """Device times (ms) of the pair launches since the previous call (after sync); clears the log."""
+        buf = (ctypes.c_double * cap)()
+        k = self._L.snk_pairs_ms_log(self._h, buf, cap)
+        if k < 0:
+            self._check(k, "snk_pairs_ms_log")
+        return [float(buf[i]) for i in range(min(k, cap))]

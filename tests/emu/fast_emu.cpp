@@ -67,14 +67,30 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         singles[g] = 0;
         if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
         SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
-        snk_fast_kernel_body<false>(T, &jb, 1u, 1u, singles, status.data());
+        SnkFastGrid G; G.jobs = &jb; G.n_jobs = 1u; G.r0 = 0u; G.rows = 1u; G.n = 1u; G.batch = 1u; G.queue = nullptr; G.yorder = nullptr;
+        snk_fast_kernel_body<false>(T, G, 1u, singles, status.data());
     }
+    // all eligible pairs as ONE launch of one lane: the lane walks the job list through the kernel's own
+    // hand-out loop (a finished lane takes the next job), alternately as an explicit list and, when every
+    // pair of the set is eligible, as a dense tile
+    std::vector<SnkJob> list;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             pairs[(size_t)i * n + j] = 0;
             if (!ok[i] || !ok[j] || lens[i] + lens[j] <= SNK_BLOCK) continue;
             SnkJob jb; jb.xi = i; jb.yi = j; jb.out_idx = (uint32_t)((size_t)i * n + j); jb.snap = 0;
-            snk_fast_kernel_body<false>(T, &jb, 1u, 1u, pairs, status.data());
+            list.push_back(jb);
         }
+    if (!list.empty()) {
+        SnkFastGrid G; G.r0 = 0u; G.rows = (uint32_t)n; G.n = (uint32_t)n; G.batch = 3u;
+        std::vector<uint32_t> order((size_t)n);
+        for (int k = 0; k < n; ++k) order[(size_t)k] = (uint32_t)(n - 1 - k);
+        G.yorder = (n & 2) ? order.data() : nullptr;
+        uint32_t counter = 1u;                           // one wave in the launch: the queue starts at 1
+        G.queue = (n & 1) ? &counter : nullptr;          // both schedules get exercised
+        if (list.size() == (size_t)n * n) { G.jobs = nullptr; G.n_jobs = (uint32_t)(n * n); }
+        else                              { G.jobs = list.data(); G.n_jobs = (uint32_t)list.size(); }
+        snk_fast_kernel_body<false>(T, G, 1u, pairs, status.data());
+    }
     return (int)status[0];
 }

@@ -21,6 +21,7 @@ static inline int __all(int p) { return p != 0; }
 static inline int __shfl(int v, int) { return v; }
 static inline void __syncthreads() {}
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t atomicAnd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o & v; return o; }
 
 static inline uint32_t snk_emu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)

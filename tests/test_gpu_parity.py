@@ -274,6 +274,39 @@ def test_row_tiles_and_pair_lists_agree_with_full_matrix(hip, oracle_mod):
     assert np.array_equal(full, exp)
 
 
+def test_interleaved_async_launches_and_schedules(hip, oracle_mod):
+    """snk_pairs_device from two streams, interleaved, on a dense set (no job list on the device) and
+    on a mixed set (the job list buffer is shared per context: the second launch must wait for the
+    first one's copy); static round-robin and atomic-queue hand-out of batches; per-launch times."""
+    import torch
+    o = oracle_mod
+    dense = [o.lcg_genome(90 + k, 70000 + 31000 * k) for k in range(7)]
+    mixed = dense[:5] + [np.frombuffer(bytes(o.lcg_genome(99, 90000)).replace(b"ACGTA", b"ACNTA"), dtype=np.uint8),
+                         o.lcg_genome(98, 30000)]
+    dev = torch.device("cuda", 0)
+    for seqs in (dense, mixed):
+        n = len(seqs)
+        exp = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+        for dyn in (0, 1):
+            with hip.HipContext(0, fast_dynamic=dyn, fast_lanes=3, fast_waves=2) as ctx:
+                ctx.upload(seqs)
+                s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+                t1 = torch.zeros((4, n), dtype=torch.int32, device=dev)
+                t2 = torch.zeros((n - 4, n), dtype=torch.int32, device=dev)
+                t3 = torch.zeros((2, n), dtype=torch.int32, device=dev)
+                ctx.pairs_device(0, 4, t1.data_ptr(), s1.cuda_stream)
+                ctx.pairs_device(4, n, t2.data_ptr(), s2.cuda_stream)
+                ctx.pairs_device(1, 3, t3.data_ptr(), s1.cuda_stream)
+                ctx.sync(s1.cuda_stream)
+                ctx.sync(s2.cuda_stream)
+                ms = ctx.pairs_ms_log()
+                assert len(ms) == 3 and all(v > 0 for v in ms)
+                assert ctx.pairs_ms_log() == []
+                got = np.concatenate([t1.cpu().numpy(), t2.cpu().numpy()]).view(np.uint32)
+                assert np.array_equal(got, exp), (dyn, np.argwhere(got != exp)[:6].tolist())
+                assert np.array_equal(t3.cpu().numpy().view(np.uint32), exp[1:3])
+
+
 def test_python_api_single_items(hip, golden):
     """compressed_size(path | (path, path), "lz4") -- the reference's granularity."""
     from pathlib import Path
