@@ -90,6 +90,10 @@ int snk_upload(snk_ctx *ctx, int n_seq, const uint8_t *const *seqs, const uint64
 /* Number of sequences resident / how many of them took the 2-bit path / distinct 5-byte hash
  * values in the resident set when the byte kernel can use its compact table (0 otherwise). */
 int snk_num_sequences(const snk_ctx *ctx);
+
+/* Lengths (bytes) of the resident sequences, in upload order, into lens[snk_num_sequences()].
+ * Host callers shard rows by work with them (snacc_amd/distributed.py).  Returns SNK_OK. */
+int snk_lengths(const snk_ctx *ctx, uint64_t *lens);
 int snk_num_packed(const snk_ctx *ctx);
 int snk_num_compact_hashes(const snk_ctx *ctx);
 

@@ -109,31 +109,58 @@ def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
     return gpu_matrix(files, "lz4", reverse_complement, show_progress, save_directory)
 
 
-def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directory=None):
+def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directory=None, ctx_factory=None,
+               backend="nccl"):
     """Phases A-C for ``-c lz4`` / ``gzip`` / ``zlib`` on the HIP backend.  Returns the float64 NCD
-    matrix in `files` order on rank 0 (None on other ranks)."""
-    from .hip_backend import HipContext, DEFLATE
+    matrix in `files` order on rank 0 (None on other ranks).
+
+    Under torchrun (WORLD_SIZE > 1) every rank uploads all files, computes its block of rows (blocks of
+    equal work, snacc_amd/distributed.py) and takes part in the all-gather; banners, progress bars and
+    files are rank 0's.  `ctx_factory` / `backend` exist for the CPU tests (a checker-provided context on
+    gloo); the product passes neither.  The multi-rank path has NOT run on RCCL yet."""
+    from .hip_backend import DEFLATE
 
     world, rank = _dist_env()
-    click.secho("Compressing individual files...", fg="green")
+    chatty = rank == 0
+    if chatty:
+        click.secho("Compressing individual files...", fg="green")
     n = len(files)
-    ctx = HipContext(int(os.environ.get("LOCAL_RANK", "0")))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    started_group = False
+    if world > 1:
+        # rendezvous BEFORE anything touches the GPU; a failure ends the run with status 3 and a message
+        import torch.distributed as dist
+        from .distributed import init_process_group
+        if not dist.is_initialized():
+            device = None
+            if backend == "nccl":
+                import torch
+                device = torch.device("cuda", local)
+            init_process_group(backend, device)
+            started_group = True
+    if ctx_factory is None:
+        from .hip_backend import HipContext
+        ctx_factory = HipContext
+    ctx = ctx_factory(local)
     try:
         # every file is parsed ONCE, by host threads inside the library (SURVEY.md 8f N1), then
         # uploaded; phase A (singles + prefix snapshots) runs as part of the upload
         ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
         deflate = algorithm in DEFLATE
         singles = (ctx.deflate_singles(algorithm) if deflate else ctx.singles()).astype(np.int64) + GETSIZEOF_OVERHEAD
-        click.secho("Compressing pairs...", fg="green")
-        if deflate and world > 1:
-            import torch
-            import torch.distributed as dist
-            from .distributed import all_pairs_deflate_hip
-            torch.cuda.set_device(ctx.device)
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device))
-            pairs = all_pairs_deflate_hip(ctx, n, algorithm).astype(np.int64) + GETSIZEOF_OVERHEAD
+        if chatty:
+            click.secho("Compressing pairs...", fg="green")
+        if world > 1:
+            from .distributed import all_pairs_deflate_hip, all_pairs_hip
+            if backend == "nccl":
+                import torch
+                torch.cuda.set_device(ctx.device)
+            lengths = ctx.lengths()
+            if deflate:
+                pairs = all_pairs_deflate_hip(ctx, n, algorithm, lengths=lengths)
+            else:
+                pairs = all_pairs_hip(ctx, n, lengths=lengths)
+            pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
         elif deflate:
             tile = max(1, (1 << 18) // max(n, 1))
             starts = range(0, n, tile)
@@ -142,19 +169,10 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
             pairs = (np.concatenate([ctx.deflate_pairs(algorithm, r0, min(n, r0 + tile)) for r0 in starts])
                      if n else np.zeros((0, 0), np.uint32))
             pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
-        elif world > 1:
-            import torch
-            import torch.distributed as dist
-            from .distributed import all_pairs_hip
-            torch.cuda.set_device(ctx.device)
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device))
-            pairs = all_pairs_hip(ctx, n).astype(np.int64) + GETSIZEOF_OVERHEAD
         else:
-            # row tiles (a multiple of the 84 chains of a workgroup) so that --show-progress has
-            # something to show on large inputs; results are identical to one call
-            tile = 84 * max(1, (1 << 21) // max(84 * n, 1))
+            # row tiles so that --show-progress has something to show on large inputs; results are
+            # identical to one call
+            tile = max(1, (1 << 21) // max(n, 1))
             starts = range(0, n, tile)
             if show_progress and n > tile:
                 starts = tqdm(starts, total=(n + tile - 1) // tile)
@@ -164,6 +182,10 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
             save_lz4_blobs(ctx, files, save_directory)
     finally:
         ctx.close()
+        if started_group:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
     if rank != 0:
         return None
     return ncd_matrix(singles, pairs)
@@ -203,7 +225,10 @@ def threadpool_matrix(files, compression, num_threads, save_compression, reverse
 @click.option("-n", "--num-threads", "numThreads", type=int, default=None,
               help="Number of Threads to use (default 5 * number of cores).")
 @click.option("-o", "--output", type=click.Path(dir_okay=False, exists=False),
-              help="The location for the output CSV file.", prompt="Output CSV path")
+              help="The location for the output CSV file.", required=True,
+              # the reference prompts when -o is missing (ref:snacc/cli.py:51-56); under torchrun every rank
+              # would prompt, so a multi-rank run requires the option instead
+              prompt="Output CSV path" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else False)
 @click.option("-s", "--save-compression", "saveCompression",
               type=click.Path(dir_okay=True, file_okay=False, resolve_path=True), default=None,
               help="Save compressed sequence files to the specified directory.")
@@ -224,7 +249,7 @@ def cli(sequences, fasta, directories, numThreads, compression, showProgress, sa
     if lz4ContentSize is not None:          # read by HipContext when it is created
         os.environ["SNACC_LZ4_CONTENT_SIZE"] = "1" if lz4ContentSize else "0"
 
-    if fasta or directories:
+    if (fasta or directories) and _dist_env()[1] == 0:
         click.secho("Warning: the -f and -d flags are deprecated and will be removed before release. "
                     "Please pass files and paths directly without the flags.", fg="yellow")
     if saveCompression:

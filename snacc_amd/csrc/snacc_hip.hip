@@ -523,6 +523,12 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
 
 int snk_num_sequences(const snk_ctx *c) { return c ? c->n : SNK_E_ARG; }
 int snk_num_packed(const snk_ctx *c) { return c ? c->n_packed : SNK_E_ARG; }
+int snk_lengths(const snk_ctx *c, uint64_t *lens)
+{
+    if (!c || (c->n && !lens)) return SNK_E_ARG;
+    for (int g = 0; g < c->n; ++g) lens[g] = c->len[(size_t)g];
+    return SNK_OK;
+}
 int snk_num_compact_hashes(const snk_ctx *c) { return c ? (c->compact_ok ? c->n_hashes : 0) : SNK_E_ARG; }
 
 int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens)

@@ -20,7 +20,7 @@ ABI_VERSION = 1
 #: every symbol ``include/snacc_hip.h`` declares (checked by the CPU test-suite)
 EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
-    "snk_upload", "snk_num_sequences", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
+    "snk_upload", "snk_num_sequences", "snk_lengths", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms", "snk_pairs_ms_log",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
     "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_pairs_device", "snk_deflate_last_ms",
@@ -87,6 +87,8 @@ def load():
     L.snk_upload.argtypes = [vp, i32, vp, vp]
     L.snk_num_sequences.restype = i32
     L.snk_num_sequences.argtypes = [vp]
+    L.snk_lengths.restype = i32
+    L.snk_lengths.argtypes = [vp, vp]
     L.snk_num_packed.restype = i32
     L.snk_num_packed.argtypes = [vp]
     L.snk_num_compact_hashes.restype = i32
@@ -242,6 +244,12 @@ class HipContext:
             _raise_fasta(self._L, rc)
         self.n = n
         return self
+
+    def lengths(self):
+        """Lengths of the resident sequences (uint64 array)."""
+        out = np.zeros(self.n, dtype=np.uint64)
+        self._check(self._L.snk_lengths(self._h, out.ctypes.data), "snk_lengths")
+        return out
 
     @property
     def num_packed(self):

@@ -1,6 +1,11 @@
-"""Multi-rank assembly path on the gloo backend, world_size 2, CPU tensors.
-The per-rank size provider is the oracle (the checker); the sharding, padding and all-gather
-code is the product's (snacc_amd/distributed.py)."""
+"""Multi-rank path on the gloo backend with CPU tensors, world sizes 2 and 3.
+
+What runs here is the PRODUCT's code -- snacc_amd/distributed.py (work-balanced row blocks, padded
+per-tile all-gathers, allgather_check as bench.py uses it) and snacc_amd/cli.gpu_matrix (every rank
+uploads, rank 0 alone reports and returns the matrix, the group it started is destroyed) -- with a
+checker-provided size provider (the oracle) standing in for the HIP context.  RCCL itself cannot be
+exercised without a multi-GPU node."""
+import ctypes
 import os
 import sys
 from pathlib import Path
@@ -12,43 +17,72 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _worker(rank, world, port, n, length, outdir):
-    sys.path.insert(0, str(ROOT))
-    import torch.distributed as dist
+def _seqs(n, length):
     import oracle
-    from oracle.loader import pairs_mt
-    from snacc_amd.distributed import all_pairs_sharded
+    return [oracle.lcg_genome(100 + i, length + 997 * (i % 4) * (i + 1)) for i in range(n)]
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    seqs = [oracle.lcg_genome(100 + i, length + 37 * i) for i in range(n)]
+    os.environ["WORLD_SIZE"], os.environ["RANK"], os.environ["LOCAL_RANK"] = str(world), str(rank), "0"
+
+
+def _worker_sharded(rank, world, port, n, length, outdir, weighted, tile_rows):
+    _init(rank, world, port)
+    import torch
+    import torch.distributed as dist
+    from oracle.loader import pairs_mt
+    from snacc_amd.distributed import (all_pairs_sharded, allgather_check, gather_tile, init_process_group,
+                                       lz4_row_weights)
+    init_process_group("gloo")
+    seqs = _seqs(n, length)
     calls = []
 
     def rows_fn(r0, r1):
         calls.append((r0, r1))
-        return pairs_mt(seqs, r0, r1, 2) if r1 > r0 else np.zeros((0, n), dtype=np.uint32)
+        return pairs_mt(seqs, r0, r1, 2)
 
-    full = all_pairs_sharded(n, rows_fn)
+    weights = lz4_row_weights([len(s) for s in seqs]) if weighted else None
+    full = all_pairs_sharded(n, rows_fn, weights=weights, tile_rows=tile_rows)
     np.save(os.path.join(outdir, f"full_{rank}.npy"), full)
-    np.save(os.path.join(outdir, f"rows_{rank}.npy"), np.array(calls))
+    np.save(os.path.join(outdir, f"rows_{rank}.npy"), np.array(calls, dtype=np.int64).reshape(-1, 2))
+    # bench.py's step: one tile per rank, gathered, checked on every rank
+    tile = torch.full((3, n), rank + 1, dtype=torch.int32)
+    gathered, _ = gather_tile(tile, world)
+    ok = allgather_check(gathered, tile, rank, world)
+    bad = gathered.clone()
+    if rank == world - 1:
+        bad[rank * 3, 0] += 1                                        # ONE rank sees a wrong slot: every rank must learn it
+    bad_ok = allgather_check(bad, tile, rank, world)
+    np.save(os.path.join(outdir, f"check_{rank}.npy"), np.array([ok, bad_ok, int(gathered[:, 0].sum())]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [5, 6, 1])
-def test_two_rank_allgather_matches_single_process(tmp_path, n):
-    import oracle
+@pytest.mark.parametrize("world,n,weighted,tile_rows", [(2, 5, False, None), (2, 6, True, 2), (2, 1, False, None),
+                                                        (3, 7, True, 1), (3, 8, False, 2), (3, 2, True, None)])
+def test_allgather_assembly_matches_single_process(tmp_path, world, n, weighted, tile_rows):
     from oracle.loader import pairs_mt
-    length, world = 3000, 2
-    port = 29500 + (os.getpid() + n) % 2000
-    mp.spawn(_worker, args=(world, port, n, length, str(tmp_path)), nprocs=world, join=True)
-    seqs = [oracle.lcg_genome(100 + i, length + 37 * i) for i in range(n)]
+    from snacc_amd.distributed import lz4_row_weights, shard_rows, shard_rows_weighted
+    length = 3000
+    port = 29500 + (os.getpid() * 7 + n * 13 + world) % 2000
+    mp.spawn(_worker_sharded, args=(world, port, n, length, str(tmp_path), weighted, tile_rows), nprocs=world, join=True)
+    seqs = _seqs(n, length)
     want = pairs_mt(seqs, 0, n, 2)
-    rows = []
+    blocks = (shard_rows_weighted(lz4_row_weights([len(s) for s in seqs]), world) if weighted
+              else [shard_rows(n, world, r)[:2] for r in range(world)])
+    covered = []
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
-        rows.append(tuple(np.load(tmp_path / f"rows_{r}.npy")[0]))
-    per = (n + world - 1) // world
-    assert rows == [(0, min(per, n)), (min(per, n), n)]
+        rows = np.load(tmp_path / f"rows_{r}.npy")
+        for a, b in rows:
+            assert blocks[r][0] <= a < b <= blocks[r][1]
+            covered += list(range(a, b))
+        ok, bad_ok, colsum = np.load(tmp_path / f"check_{r}.npy")
+        assert ok == 1 and bad_ok == 0 and colsum == 3 * sum(range(1, world + 1))
+    assert sorted(covered) == list(range(n))
 
 
 def test_shard_rows_cover_everything():
@@ -61,3 +95,118 @@ def test_shard_rows_cover_everything():
                 assert r1 - r0 <= per
                 got += list(range(r0, r1))
             assert got == list(range(n))
+
+
+def test_weighted_shards_balance_ragged_lengths():
+    """rows are cut by work, not by count.  On ragged genome lengths every rank's share of the
+    lz4 work stays within one row of the ideal; equal counts do not."""
+    from snacc_amd.distributed import lz4_row_weights, shard_rows, shard_rows_weighted
+    rng = np.random.default_rng(3)
+    for world in (2, 3, 8):
+        lengths = np.sort(rng.integers(500_000, 1_500_000, 1024))          # sorted by size: file order often is
+        w = lz4_row_weights(lengths)
+        blocks = shard_rows_weighted(w, world)
+        assert blocks[0][0] == 0 and blocks[-1][1] == 1024 and all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        share = np.array([w[a:b].sum() for a, b in blocks])
+        assert share.max() <= w.sum() / world + w.max()
+        # a codec without prefix reuse costs len_i * sum_j len_j per row (SURVEY.md 8e): there equal counts are far off
+        w2 = lengths.astype(np.float64) * lengths.sum()
+        blocks2 = shard_rows_weighted(w2, world)
+        share2 = np.array([w2[a:b].sum() for a, b in blocks2])
+        by_count = np.array([w2[slice(*shard_rows(1024, world, r)[:2])].sum() for r in range(world)])
+        assert share2.max() <= w2.sum() / world + w2.max() < by_count.max()
+    assert shard_rows_weighted([], 3) == [(0, 0)] * 3
+    assert shard_rows_weighted([0, 0, 0, 0], 2) == [(0, 2), (2, 4)]
+    assert shard_rows_weighted([5.0], 3)[-1][1] == 1
+
+
+class _CheckerContext:
+    """Stands in for HipContext in cli.gpu_matrix: sizes from the oracle, written where the caller says."""
+    def __init__(self, device):
+        import torch
+        self.device = device
+        self.torch_device = torch.device("cpu")
+        self.seqs = []
+        self.closed = False
+
+    def upload_fasta(self, paths, reverse_complement=False):
+        from snacc_amd import fasta
+        self.seqs = [np.frombuffer(fasta.read_sequence(p, reverse_complement).encode(), dtype=np.uint8) for p in paths]
+        self.n = len(self.seqs)
+
+    def lengths(self):
+        return np.array([len(s) for s in self.seqs], dtype=np.uint64)
+
+    def singles(self):
+        import oracle
+        return np.array([oracle.lz4f_size(s) for s in self.seqs], dtype=np.uint32)
+
+    def pairs_device(self, r0, r1, ptr, stream):
+        from oracle.loader import pairs_mt
+        a = np.ascontiguousarray(pairs_mt(self.seqs, r0, r1, 2))
+        ctypes.memmove(ptr, a.ctypes.data, a.nbytes)
+
+    def sync(self, stream):
+        pass
+
+    def close(self):
+        self.closed = True
+
+
+def _worker_cli(rank, world, port, fadir, outdir):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from click.testing import CliRunner
+    from snacc_amd import cli as cli_mod
+    made = []
+
+    def factory(dev):
+        made.append(_CheckerContext(dev))
+        return made[-1]
+
+    real = cli_mod.gpu_matrix
+    cli_mod.gpu_matrix = lambda *a, **k: real(*a, ctx_factory=factory, backend="gloo", **k)
+    out = Path(outdir) / f"out_{rank}.csv"
+    os.chdir(outdir)
+    res = CliRunner().invoke(cli_mod.cli, [fadir, "-o", str(out), "-c", "lz4", "--no-show-progress", "--no-log"])
+    Path(outdir, f"cli_{rank}.txt").write_text(f"{res.exit_code}\n{int(out.exists())}\n{int(dist.is_initialized())}\n"
+                                               f"{int(made[0].closed)}\n{res.output}\n{res.exception!r}")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cli_multi_rank_only_rank0_reports_and_writes(tmp_path, world):
+    import oracle
+    from conftest import write_fasta
+    from snacc_amd.matrix import ncd_matrix
+    fadir = tmp_path / "fa"
+    fadir.mkdir()
+    seqs = _seqs(5, 20000)
+    for k, sq in enumerate(seqs):
+        write_fasta(fadir / f"g{k}.fasta", [("r", bytes(sq).decode())])
+    port = 31500 + (os.getpid() * 3 + world) % 2000
+    mp.spawn(_worker_cli, args=(world, port, str(fadir), str(tmp_path)), nprocs=world, join=True)
+    singles = np.array([oracle.lz4f_size(s) for s in seqs], dtype=np.int64) + 33
+    pairs = np.array([[oracle.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.int64) + 33
+    want = ncd_matrix(singles, pairs)
+    for r in range(world):
+        code, wrote, still_init, closed, *output = (tmp_path / f"cli_{r}.txt").read_text().split("\n")
+        assert code == "0" and still_init == "0" and closed == "1", (r, output)
+        assert wrote == ("1" if r == 0 else "0")
+        assert ("Compressing pairs..." in "\n".join(output)) == (r == 0)
+    got = np.loadtxt(tmp_path / "out_0.csv", delimiter=",", skiprows=1, usecols=range(1, 6))
+    assert np.array_equal(got, want)
+
+
+def test_failed_rendezvous_exits_non_zero(tmp_path):
+    """A rank that cannot join the group ends with status 3 and says why (no silent single-rank result)."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='1', WORLD_SIZE='2', RANK='1')\n"
+            "from snacc_amd.distributed import init_process_group\n"
+            "import datetime, torch.distributed as dist\n"
+            "real = dist.init_process_group\n"
+            "dist.init_process_group = lambda *a, **k: real(*a, timeout=datetime.timedelta(seconds=2), **k)\n"
+            "init_process_group('gloo')\n" % str(ROOT))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 3
+    assert "init_process_group(gloo) failed" in res.stderr
