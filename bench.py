@@ -4,10 +4,17 @@
 One "step" = one pass of the hot path over one batch: the frame sizes of
 ``rows_per_step x N`` ordered genome pairs (a tile of rows of the N x N matrix
 of ref:snacc/cli.py:120-129) against the N synthetic genomes resident in HBM,
-followed -- when more than one rank runs -- by the RCCL all-gather of the tile.
+followed -- when more than one rank runs -- by the RCCL all-gather of the tile
+(issued asynchronously: the gather of step k runs under the kernel of step k+1).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+``value`` is the weak-scaling rate of the timed steps (driver contract).  After the timed region the
+run also MEASURES the second half of BASELINE.json's metric, the wall time of one full N x N matrix
+(``matrix_wall_s``: upload, singles + prefix snapshots, all N rows split over the ranks, the gather,
+D2H, NCD assembly -- strong scaling), and times the CPU baselines.  ``--mode strong`` makes the matrix
+run the reported value instead.
 
 ``--codec gzip|zlib`` measures the deflate path the same way; the default and
 the headline metric is lz4.
@@ -20,6 +27,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,6 +37,12 @@ sys.path.insert(0, ROOT)
 
 LCG_A = 6364136223846793005
 LCG_C = 1442695040888963407
+
+# Model of the bound that actually limits the 2-bit kernel: one probe per trip of the
+# steady loop for each of the chains resident on a CU; a trip cannot be shorter than the dependent chain of a
+# probe: 33 instructions on the chain at 4.2 cycles (one wave per SIMD) + table read + candidate window + slot LUT.
+LAT_MODEL = {"chain_instructions": 33, "cycles_per_instruction": 4.2, "lds_table_cycles": 60, "l1_window_cycles": 180,
+             "lds_lut_cycles": 64, "chains_per_cu": 84, "cus": 256, "clock_hz": 2.4e9}
 
 
 def lcg_genomes_torch(n_genomes, length, seed0, device):
@@ -47,19 +61,118 @@ def lcg_genomes_torch(n_genomes, length, seed0, device):
     return out
 
 
-def pmc_traffic_bytes(rows, n, length, codec="lz4"):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_pmc_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE doubled per the gfx950
-    calibration of MI355X_MICROARCH.md).  Only valid for the launch shape it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if codec == "lz4" else f"r01_pmc_traffic_{codec}.json")
+def pmc_traffic(rows, n, length, codec="lz4"):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of THIS round's kernel
+    (profiles/r02_pmc_traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE
+    doubled per the gfx950 calibration of MI355X_MICROARCH.md; the file names the commit it was taken at).
+    Only valid for the launch shape it was collected on; None otherwise."""
+    name = "r02_pmc_traffic.json" if codec == "lz4" else f"r02_pmc_traffic_{codec}.json"
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             t = json.load(f)
         if (t["rows"], t["genomes"], t["length"]) == (rows, n, length):
-            return t["hbm_bytes_per_launch"]
+            return t["hbm_bytes_per_launch"], f"profiles/{name} @ {t.get('collected_at_commit', '?')}"
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
+
+
+def host_cores():
+    """(threads this process may run on, physical cores they sit on)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    phys = set()
+    try:
+        cur = {}
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if not line.strip():
+                    if "processor" in cur and int(cur["processor"]) in cpus:
+                        phys.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                    cur = {}
+                elif ":" in line:
+                    k, v = line.split(":", 1)
+                    cur[k.strip()] = v.strip()
+    except OSError:
+        pass
+    return len(cpus), (len(phys) or len(cpus))
+
+
+def cpu_baseline_lz4(genomes, length, budget_s):
+    """B2: the oracle's C restatement, one preallocated buffer + stream state per thread, for `budget_s`
+    seconds on every thread this process may use.  B3 (when a liblz4 binary exists on the box): the same
+    loop on LZ4F_compressFrame itself."""
+    from oracle.loader import pairs_timed
+    threads, phys = host_cores()
+    sub = genomes[:64]
+    done, dt = pairs_timed(sub, threads, budget_s)
+    out = {"value": done / dt / 2.0, "unit": "NCD/s", "cores": threads, "physical_cores": phys, "kind": "port",
+           "pair_compressions_per_s": done / dt,
+           "sample": f"{done} ordered pairs of {length} bp genomes (drawn from the first {len(sub)}), oracle C restatement, "
+                     f"{threads} pthreads with preallocated buffers, {dt:.1f} s wall"}
+    try:
+        from oracle import liblz4_ref
+        if liblz4_ref.available():
+            import ctypes
+            L = liblz4_ref._load()
+            raw = [bytes(g) for g in sub[:16]]
+            counts = [0] * threads
+            budget3 = max(2.0, budget_s / 2)
+            t0 = time.perf_counter()
+
+            def work(t):
+                bufs = [raw[(t + k) % len(raw)] + raw[(7 * t + 3 * k + 1) % len(raw)] for k in range(4)]
+                cap = L.LZ4F_compressFrameBound(len(bufs[0]), None)
+                dst = ctypes.create_string_buffer(cap)
+                k = 0
+                while time.perf_counter() - t0 < budget3:
+                    L.LZ4F_compressFrame(dst, cap, bufs[k & 3], len(bufs[k & 3]), None)      # ctypes drops the GIL
+                    counts[t] += 1
+                    k += 1
+
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            dt3 = time.perf_counter() - t0
+            out["liblz4"] = {"pair_compressions_per_s": sum(counts) / dt3, "version": liblz4_ref.version(),
+                             "sample": f"{sum(counts)} x LZ4F_compressFrame(2 x {length} B, NULL prefs), {threads} threads, {dt3:.1f} s"}
+    except Exception as e:                                  # noqa: BLE001  (optional leg)
+        out["liblz4"] = {"error": repr(e)}
+    return out
+
+
+def cpu_baseline_deflate(genomes, length, codec, budget_s):
+    """The codec the reference itself calls (stdlib gzip / zlib, GIL released), one thread per usable core."""
+    import gzip as _gzip
+    import zlib as _zlib
+    fn = {"gzip": _gzip.compress, "zlib": _zlib.compress}[codec]
+    threads, phys = host_cores()
+    raw = [bytes(g) for g in genomes[:64]]
+    counts = [0] * threads
+    t0 = time.perf_counter()
+
+    def work(t):
+        i = t
+        while time.perf_counter() - t0 < budget_s:
+            fn(raw[i % len(raw)] + raw[(7 * i + 1) % len(raw)])
+            counts[t] += 1
+            i += threads
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    npairs = sum(counts)
+    return {"value": npairs / dt / 2.0, "unit": "NCD/s", "cores": threads, "physical_cores": phys, "kind": "reference",
+            "pair_compressions_per_s": npairs / dt,
+            "sample": f"{npairs} ordered pairs of {length} bp genomes, {codec}.compress of the interpreter "
+                      f"(zlib {_zlib.ZLIB_RUNTIME_VERSION}), {threads} threads, {dt:.1f} s wall"}
 
 
 def main():
@@ -70,38 +183,41 @@ def main():
     ap.add_argument("--genomes", type=int, default=1024, help="N (BASELINE configs[2]: 1024)")
     ap.add_argument("--length", type=int, default=1_000_000, help="bases per genome (configs[2]: 1 Mbp)")
     ap.add_argument("--rows-per-step", type=int, default=84, help="rows of the N x N matrix per step and rank")
+    ap.add_argument("--mode", choices=["weak", "strong"], default="weak",
+                    help="weak (default, driver contract): fixed rows per rank per step; strong: value = the measured full-matrix run")
     ap.add_argument("--lanes", type=int, default=0, help="override fast_lanes")
     ap.add_argument("--waves", type=int, default=0, help="override fast_waves")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="extra backend option key=value (repeatable)")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matrix", action="store_true", help="skip the measured full-matrix run")
     ap.add_argument("--codec", choices=["lz4", "gzip", "zlib"], default="lz4")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     # SNACC_BENCH_REHEARSE=1: exercise the multi-rank code path on ONE GPU (all ranks on device 0,
     # gloo with host staging for the gather).  Never used for reported numbers.
     rehearse = os.environ.get("SNACC_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+
+    import torch
+    import torch.distributed as dist
+    from snacc_amd import distributed as sdist
+
+    # Rendezvous first: nothing touches the GPU before the process group exists, and a failure ends the run
+    # with status 3 and a message on stderr (snacc_amd.distributed.init_process_group).
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        sdist.init_process_group("gloo" if rehearse else "nccl", None if rehearse else dev)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
 
     from snacc_amd.hip_backend import HipContext
 
@@ -133,102 +249,142 @@ def main():
     rows_per_rank = N // world
     shard0 = rank * rows_per_rank
     # An explicit (non-default) torch stream: its handle is what the C-ABI launches on, and it is the
-    # current stream for the RCCL all-gather, so the collective is ordered after the kernel.  (The
+    # current stream when the collective is issued, so the gather is ordered after the kernel.  (The
     # default stream's handle is 0, which the C-ABI reads as "use the context's own stream".)
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    tile = torch.zeros((R, N), dtype=torch.int32, device=dev)     # u32 sizes, viewed as int32
-    gathered = torch.zeros((world * R, N), dtype=torch.int32, device=dev) if world > 1 else None
+    # two tiles / two gather targets: the asynchronous gather of step k overlaps the kernel of step k+1
+    tiles = [torch.zeros((R, N), dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((world * R, N), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else [None, None]
+    pending = [None, None]
 
-    def gather():
+    def gather(slot):
         if world == 1:
             return
-        if rehearse:                                   # gloo: stage through the host
+        if rehearse:                                   # gloo: stage through the host (synchronous)
             stream.synchronize()
-            parts = [torch.zeros((R, N), dtype=torch.int32) for _ in range(world)]
-            dist.all_gather(parts, tile.cpu())
-            gathered.copy_(torch.cat(parts).to(dev))
+            g, _ = sdist.gather_tile(tiles[slot].cpu(), world)
+            gathered[slot].copy_(g.to(dev))
         else:
-            dist.all_gather_into_tensor(gathered, tile)
+            _, pending[slot] = sdist.gather_tile(tiles[slot], world, out=gathered[slot], async_op=True)
 
     kern_ms = []
 
-    def launch(r0):
+    def launch(r0, slot):
+        if pending[slot] is not None:                    # the gather that last read this tile must be done
+            pending[slot].wait()
+            pending[slot] = None
         if deflate:                                      # raw deflate stream sizes straight into the device tile
-            ctx.deflate_pairs_device(args.codec, r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+            ctx.deflate_pairs_device(args.codec, r0, r0 + R, tiles[slot].data_ptr(), stream.cuda_stream)
             kern_ms.append(ctx.deflate_last_ms())        # (waits for this launch: its event pair)
         else:
-            ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+            ctx.pairs_device(r0, r0 + R, tiles[slot].data_ptr(), stream.cuda_stream)
 
-    def step(k):
-        r0 = shard0 + (k * R) % max(rows_per_rank - R + 1, 1)
-        launch(r0)
-        gather()
-        return r0
+    def row0(k):
+        return shard0 + (k * R) % max(rows_per_rank - R + 1, 1)
+
+    def drain():
+        for s in (0, 1):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
 
     def fence():
+        drain()
         if world > 1:
-            dist.barrier()
+            try:
+                dist.barrier()
+            except Exception as e:                       # noqa: BLE001
+                sdist._die("barrier", e)
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
-        step(k)
+        launch(row0(k), k & 1)
+        gather(k & 1)
     fence()
     ctx.sync(stream.cuda_stream)
     kern_ms.clear()
+    if not deflate:
+        ctx.pairs_ms_log()                                # forget the warm-up launches
 
-    # HIP events on the stream the kernels are launched on (torch's current stream is passed to the
-    # C-ABI).  One pair around the whole timed region: per-launch pairs under-report back-to-back
-    # launches (the "start" marker of launch k+1 is stamped while launch k is still draining).
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
-    last_r0 = 0
+    last_r0, last_slot = 0, 0
     ev_begin.record(stream)
     for k in range(args.steps):
-        r0 = shard0 + ((args.warmup + k) * R) % max(rows_per_rank - R + 1, 1)
-        launch(r0)
-        gather()
-        last_r0 = r0
+        r0 = row0(args.warmup + k)
+        launch(r0, k & 1)
+        gather(k & 1)
+        last_r0, last_slot = r0, k & 1
     ev_end.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
-    ctx.sync(stream.cuda_stream)                          # raises if a kernel flagged an error
-    lib_last_ms = ctx.last_pairs_ms()                     # the library's own event pair, last launch
+    ctx.sync(stream.cuda_stream)                          # raises if an lz4 kernel flagged an error
+    tile = tiles[last_slot]
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    # Launch duration of the dominant kernel: the library brackets every launch with its own
-    # hipEvent pair on the launch stream (snk_last_pairs_ms); rocprofv3 --kernel-trace agrees with it
-    # (profiles/).  A torch event recorded on the idle stream before the first launch is stamped
-    # late on this ROCm build, so the region pair is kept only as a cross-check.
-    kern_ms_region = ev_begin.elapsed_time(ev_end) / args.steps
-    kern_ms_avg = lib_last_ms if lib_last_ms > 0 else kern_ms_region
-    if deflate:
-        kern_ms_avg = float(np.mean(kern_ms))
+    # Launch duration of the dominant kernel: the library brackets EVERY launch with its own hipEvent pair on
+    # the launch stream (snk_pairs_ms_log); the mean over the timed launches is reported (rocprofv3
+    # --kernel-trace agrees with it, profiles/).  The torch event pair around the region is a cross-check.
+    kern_ms_region = ev_begin.elapsed_time(ev_end) / max(args.steps, 1)
+    if not deflate:
+        kern_ms = ctx.pairs_ms_log()
+    kern_ms_avg = float(np.mean(kern_ms)) if len(kern_ms) else kern_ms_region
 
     pairs_per_step = R * N * world
     pair_rate = pairs_per_step * args.steps / elapsed
-    ncd_rate = pair_rate / 2.0                            # 1 NCD = 2 ordered pair-compressions
     alg_bytes_launch = R * N * (2 * L + 4)                # per launch (one rank): len_i + len_j read + 4 B written
     achieved = alg_bytes_launch / (kern_ms_avg * 1e-3) / 1e9
 
     gather_ok = None
     if world > 1:                                       # every rank's tile must be in its slot of the gather
-        gather_ok = bool(torch.equal(gathered[rank * R:(rank + 1) * R], tile))
-        flag = torch.tensor([1 if gather_ok else 0], dtype=torch.int32, device="cpu" if rehearse else dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gather_ok = bool(flag.item())
+        gather_ok = sdist.allgather_check(gathered[last_slot].cpu() if rehearse else gathered[last_slot],
+                                          tile.cpu() if rehearse else tile, rank, world)
+
+    # ---- the metric's second half, MEASURED: one full N x N matrix (strong scaling over the ranks) ----
+    matrix = None
+    if not args.no_matrix:
+        from snacc_amd.matrix import ncd_matrix
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        fence()
+        m0 = time.perf_counter()
+        ctx2 = HipContext(local_rank, **opts)
+        ctx2.upload(genomes)
+        singles = (ctx2.deflate_singles(args.codec) if deflate else ctx2.singles()).astype(np.int64) + 33
+        m1 = time.perf_counter()
+        if world == 1:
+            pairs = ctx2.deflate_pairs(args.codec) if deflate else ctx2.pairs()     # (deflate sizes include the wrapper bytes)
+        elif rehearse:
+            pairs = None
+        elif deflate:
+            pairs = sdist.all_pairs_deflate_hip(ctx2, N, args.codec, lengths=ctx2.lengths())
+        else:
+            pairs = sdist.all_pairs_hip(ctx2, N, lengths=ctx2.lengths())
+        m2 = time.perf_counter()
+        ncd = ncd_matrix(singles, pairs.astype(np.int64) + 33) if (rank == 0 and pairs is not None) else None
+        m3 = time.perf_counter()
+        ctx2.close()
+        wall = m3 - m0
+        if world > 1:
+            tmax = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        if pairs is not None:
+            matrix = {"matrix_wall_s": wall, "upload_and_singles_s": m1 - m0, "pairs_and_gather_s": m2 - m1, "ncd_assembly_s": m3 - m2,
+                      "ncds": N * (N + 1) // 2, "symmetric": bool(ncd is None or np.array_equal(ncd, ncd.T)),
+                      "what": "upload + singles/snapshots + all N rows (split over the ranks) + gather + D2H + float64 NCD matrix, one run"}
 
     # spot parity of the last tile against the oracle (checker only; not in the timed region)
     parity = None
     cpu_baseline = None
+    probes_per_pair = None
     if rank == 0:
         import oracle
-        from oracle.loader import pairs_mt
         host_tile = tile.cpu().numpy().view(np.uint32)
         js = [0, 1, N // 2, N - 1]
         if deflate:
@@ -237,78 +393,62 @@ def main():
             parity = all(int(host_tile[0, j]) == dfl_oracle.raw_size(genomes[last_r0], genomes[j], lvl) for j in js[:2])
         else:
             parity = all(int(host_tile[0, j]) == oracle.lz4f_size_pair(genomes[last_r0], genomes[j]) for j in js)
-        if deflate and not args.no_cpu_baseline and world == 1:
-            # the codec the reference itself calls (stdlib gzip / zlib, GIL released), one thread per core
-            import gzip as _gzip
-            import zlib as _zlib
-            fn = {"gzip": _gzip.compress, "zlib": _zlib.compress}[args.codec]
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            raw = [bytes(g) for g in genomes[:min(N, 64)]]
-            budget_s = 20.0                              # bounded sample: every thread compresses pairs until the deadline
-            import threading
-            counts = [0] * cores
-            t0 = time.perf_counter()
-
-            def work(t):
-                i = t
-                while time.perf_counter() - t0 < budget_s and (not args.cpu_sample_pairs or counts[t] * cores < args.cpu_sample_pairs):
-                    fn(raw[i % len(raw)] + raw[(7 * i + 1) % len(raw)])
-                    counts[t] += 1
-                    i += cores
-
-            threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-            for th in threads:
-                th.start()
-            for th in threads:
-                th.join()
-            dt = time.perf_counter() - t0
-            npairs = sum(counts)
-            cpu_baseline = {
-                "value": npairs / dt / 2.0, "unit": "NCD/s", "cores": cores, "kind": "reference",
-                "pair_compressions_per_s": npairs / dt,
-                "sample": f"{npairs} ordered pairs of {L} bp genomes, {args.codec}.compress of the interpreter "
-                          f"(zlib {_zlib.ZLIB_RUNTIME_VERSION}), {cores} threads, {dt:.1f} s wall",
-            }
-        elif not args.no_cpu_baseline and world == 1:
-            cores = os.cpu_count() or 1
-            per_pair_s = 8.3e-3 * (2 * L / 2e6)           # survey probe: 8.3 ms per 2 Mbp pair per core
-            want = args.cpu_sample_pairs or int(max(cores, min(20.0 / max(per_pair_s, 1e-6), 4096)))
-            rows = max(1, min(N, (want + N - 1) // N))
-            sub = genomes if rows * N <= want * 2 else genomes[:max(2, want // rows)]
-            t0 = time.perf_counter()
-            ref = pairs_mt(sub, 0, min(rows, len(sub)), cores)
-            dt = time.perf_counter() - t0
-            npairs = ref.size
-            cpu_baseline = {
-                "value": npairs / dt / 2.0, "unit": "NCD/s", "cores": cores, "kind": "port",
-                "pair_compressions_per_s": npairs / dt,
-                "sample": f"{npairs} ordered pairs ({ref.shape[0]} rows x {ref.shape[1]} genomes of {L} bp), "
-                          f"oracle C restatement, {cores} pthreads, {dt:.1f} s wall",
-            }
+            # probes of one pair job (the oracle's statistics): those of x+y minus those of the blocks of x that
+            # come from its prefix snapshot
+            from oracle.loader import lz4f_size_stats
+            xy = np.concatenate([genomes[0], genomes[1]])
+            _, st_xy = lz4f_size_stats(xy)
+            _, st_x = lz4f_size_stats(genomes[0])
+            covered = (L // 65536) * 65536 / max(L, 1) if L > 65536 else 0.0
+            probes_per_pair = (st_xy["search_probes"] + st_xy["chain_probes"]) - covered * (st_x["search_probes"] + st_x["chain_probes"])
+        if not args.no_cpu_baseline and world == 1:
+            cpu_baseline = (cpu_baseline_deflate(genomes, L, args.codec, args.cpu_seconds) if deflate
+                            else cpu_baseline_lz4(genomes, L, args.cpu_seconds))
 
     if rank == 0:
+        if args.mode == "strong" and matrix:
+            pair_rate = (N * N + N) / matrix["matrix_wall_s"]
+        ncd_rate = pair_rate / 2.0                        # 1 NCD = 2 ordered pair-compressions
+        traffic, traffic_src = pmc_traffic(R, N, L, args.codec)
+        latency_bound = None
+        if probes_per_pair:
+            mdl = LAT_MODEL
+            trip = (mdl["chain_instructions"] * mdl["cycles_per_instruction"] + mdl["lds_table_cycles"]
+                    + mdl["l1_window_cycles"] + mdl["lds_lut_cycles"])
+            peak = mdl["cus"] * mdl["chains_per_cu"] * mdl["clock_hz"] / trip
+            ach = R * N * probes_per_pair / (kern_ms_avg * 1e-3)
+            latency_bound = {"bound": "dependent-probe latency x chains resident in LDS (the limiter; HBM is idle)",
+                             "achieved": ach, "peak": peak, "unit": "probes/s per GPU", "frac": ach / peak,
+                             "probes_per_pair": probes_per_pair, "model": dict(mdl, trip_cycles=trip)}
+        par = f"row-shard x{world}"
+        if world > 1:
+            par += " + gloo all-gather (ONE-GPU REHEARSAL, not a measurement)" if rehearse else " + RCCL all-gather (async, overlapped)"
         line = {
             "metric": f"genome-pair NCDs/sec ({args.codec}, all ordered pairs; 1 NCD = 2 pair-compressions)",
             "value": ncd_rate, "unit": "NCD/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (LCG uniform ACGT, seed = 1 + genome index)",
             "config": {"workload": f"{N} synthetic {L} bp genomes, {args.codec}, rows_per_step={R} x {N} cols per GPU",
-                       "genomes": N, "length": L, "rows_per_step_per_gpu": R,
-                       "parallelism": f"row-shard x{world}" + (" + RCCL all-gather" if world > 1 else "")},
+                       "genomes": N, "length": L, "rows_per_step_per_gpu": R, "parallelism": par},
             "pair_compressions_per_s": pair_rate,
-            "matrix_wall_s_est": (N * N + N) / pair_rate,
+            "matrix_wall_s": matrix["matrix_wall_s"] if matrix else None,
+            "matrix": matrix,
+            "matrix_wall_s_est": (N * N + N) / (pairs_per_step * args.steps / elapsed),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic_bytes(R, N, L, args.codec),
-                         "kernel": "dfl_parse_kernel" if deflate else ("snk_fast_kernel" if not args.force_generic else "snk_generic_kernel"),
-                         "kernel_ms_avg": kern_ms_avg, "kernel_ms_region_torch_events": kern_ms_region,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "dfl_parse_kernel" if deflate else ("snk_fast_kernel" if not args.force_generic else "snk_bytes_compact_kernel"),
+                         "kernel_ms_avg": kern_ms_avg, "kernel_launches_averaged": len(kern_ms),
+                         "kernel_ms_region_torch_events": kern_ms_region,
                          "alg_bytes_per_launch": alg_bytes_launch},
+            "latency_bound": latency_bound,
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": parity, "allgather_check": gather_ok,
             "setup_s": {"generate": round(t_gen, 2), "upload_and_singles": round(t_upload, 2)},
         }
         print(json.dumps(line), flush=True)
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -54,6 +54,10 @@ def lib():
         L.snk_oracle_pairs_list_mt.restype = ctypes.c_int
         L.snk_oracle_pairs_list_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
                                                ctypes.c_void_p, ctypes.c_int]
+        L.snk_oracle_pairs_timed.restype = ctypes.c_int
+        L.snk_oracle_pairs_timed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_uint64)]
         _lib = L
     return _lib
 
@@ -128,3 +132,19 @@ def pairs_list_mt(seqs, ij, nthreads):
     if lib().snk_oracle_pairs_list_mt(ptrs, lens, ij.ctypes.data, len(ij), out.ctypes.data, nthreads) != 0:
         raise RuntimeError("snk_oracle_pairs_list_mt failed")
     return out
+
+
+def pairs_timed(seqs, nthreads, seconds):
+    """bench.py's CPU baseline: `nthreads` threads, each with its own preallocated buffer and stream state,
+    compress ordered pairs of `seqs` for `seconds`.  Returns (pairs completed, wall seconds)."""
+    arrs = [np.ascontiguousarray(s, dtype=np.uint8) if isinstance(s, np.ndarray)
+            else np.frombuffer(bytes(s), dtype=np.uint8) for s in seqs]
+    n = len(arrs)
+    ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    lens = (ctypes.c_uint64 * n)(*[int(a.size) for a in arrs])
+    done, el, ck = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_uint64()
+    rc = lib().snk_oracle_pairs_timed(ptrs, lens, n, int(nthreads), float(seconds), ctypes.byref(done),
+                                      ctypes.byref(el), ctypes.byref(ck))
+    if rc != 0:
+        raise RuntimeError("snk_oracle_pairs_timed failed")
+    return int(done.value), float(el.value)

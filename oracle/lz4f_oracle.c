@@ -31,6 +31,7 @@
  * real py-lz4framed wheel is UNPINNED (unknown bundled liblz4 version; unknown
  * content-size flag => possible constant +8 B): see DESIGN.md.
  */
+#define _POSIX_C_SOURCE 200809L      /* clock_gettime (timed CPU baseline) under -std=c11 */
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
@@ -371,4 +372,84 @@ int snk_oracle_pairs_list_mt(const uint8_t *const *seqs, const uint64_t *lens, c
     for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
     free(th); free(jobs);
     return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * Timed CPU baseline for bench.py (cpu_baseline leg, kind "port"): every thread owns ONE
+ * concatenation buffer and ONE stream state, allocated before the clock starts, and compresses
+ * ordered pairs (a, b) of the given sequences until `seconds` have passed.  Reports the pairs
+ * completed by all threads and the wall time of the slowest thread.
+ * ------------------------------------------------------------------------- */
+#include <time.h>
+typedef struct {
+    const uint8_t *const *seqs; const uint64_t *lens; int n;
+    double seconds; int tid, nthreads;
+    uint8_t *buf; snk_oracle_stream *st;
+    uint64_t done, checksum; double elapsed;
+} timed_job;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *timed_worker(void *arg)
+{
+    timed_job *j = (timed_job *)arg;
+    const double t0 = now_s();
+    uint64_t k = (uint64_t)j->tid;
+    for (;;) {
+        const int a = (int)(k % (uint64_t)j->n), b = (int)((k * 7u + 1u + k / (uint64_t)j->n) % (uint64_t)j->n);
+        const uint64_t nx = j->lens[a], ny = j->lens[b], n = nx + ny;
+        memcpy(j->buf, j->seqs[a], nx);                 /* the concatenation the reference builds per pair */
+        memcpy(j->buf + nx, j->seqs[b], ny);
+        if (n > SNK_BLOCK) {
+            snk_oracle_stream_init(j->st);
+            snk_oracle_stream_run(j->st, j->buf, n, n, NULL);
+            j->checksum += j->st->out + 4u;
+        } else {
+            j->checksum += snk_oracle_lz4f_size(j->buf, n);
+        }
+        j->done++;
+        k += (uint64_t)j->nthreads;
+        j->elapsed = now_s() - t0;
+        if (j->elapsed >= j->seconds) break;
+    }
+    return NULL;
+}
+
+int snk_oracle_pairs_timed(const uint8_t *const *seqs, const uint64_t *lens, int n, int nthreads,
+                           double seconds, uint64_t *pairs_done, double *elapsed, uint64_t *checksum)
+{
+    pthread_t *th;
+    timed_job *jobs;
+    uint64_t maxlen = 0;
+    int t, rc = 0;
+    if (n < 1 || nthreads < 1) return -1;
+    for (t = 0; t < n; t++) if (lens[t] > maxlen) maxlen = lens[t];
+    th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    jobs = (timed_job *)calloc((size_t)nthreads, sizeof(timed_job));
+    if (!th || !jobs) return -1;
+    for (t = 0; t < nthreads; t++) {
+        jobs[t].seqs = seqs; jobs[t].lens = lens; jobs[t].n = n; jobs[t].seconds = seconds;
+        jobs[t].tid = t; jobs[t].nthreads = nthreads;
+        jobs[t].buf = (uint8_t *)malloc(2 * maxlen + 16);
+        jobs[t].st = (snk_oracle_stream *)malloc(sizeof(snk_oracle_stream));
+        if (!jobs[t].buf || !jobs[t].st) rc = -1;
+        else memset(jobs[t].buf, 0, 2 * maxlen + 16);   /* touch the pages before the clock starts */
+    }
+    *pairs_done = 0; *elapsed = 0.0; *checksum = 0;
+    if (rc == 0) {
+        for (t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, timed_worker, &jobs[t]);
+        for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        for (t = 0; t < nthreads; t++) {
+            *pairs_done += jobs[t].done; *checksum += jobs[t].checksum;
+            if (jobs[t].elapsed > *elapsed) *elapsed = jobs[t].elapsed;
+        }
+    }
+    for (t = 0; t < nthreads; t++) { free(jobs[t].buf); free(jobs[t].st); }
+    free(th); free(jobs);
+    return rc;
 }
