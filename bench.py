@@ -77,8 +77,27 @@ def pmc_traffic(rows, n, length, codec="lz4"):
     return None, None
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
-    """(threads this process may run on, physical cores they sit on)."""
+    """(threads to run = CPUs this process may use, capped by the container's CPU quota; physical cores the
+    affinity mask spans)."""
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -97,7 +116,11 @@ def host_cores():
                     cur[k.strip()] = v.strip()
     except OSError:
         pass
-    return len(cpus), (len(phys) or len(cpus))
+    threads = len(cpus)
+    quota = cgroup_cpu_quota()
+    if quota is not None:
+        threads = max(1, min(threads, int(quota + 0.5)))
+    return threads, min(threads, len(phys) or len(cpus))
 
 
 def cpu_baseline_lz4(genomes, length, budget_s):
