@@ -109,6 +109,48 @@ def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
     return gpu_matrix(files, "lz4", reverse_complement, show_progress, save_directory)
 
 
+def blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress=False):
+    """Singles and all ordered pair sizes of a file set whose residues do not fit one upload (the device
+    arenas are addressed with 32-bit offsets: about 4.29 GB of residues, e.g. 1000 bacterial genomes of
+    5 Mbp).  The files are cut into groups of at most half the limit; every pair of groups is uploaded
+    once and its ordered pairs (both directions) are computed from a pair list.  Same sizes as one
+    upload would give (each pair is a function of its two sequences only); G(G+1)/2 uploads for G groups."""
+    from .hip_backend import DEFLATE
+    n = len(files)
+    sizes = [os.path.getsize(f) + 192 for f in files]            # >= residues + arena padding
+    cap = int(os.environ.get("SNACC_ARENA_LIMIT", str(0xFFF00000))) * 45 // 100
+    groups, cur, tot = [], [], 0
+    for i in range(n):
+        if cur and tot + sizes[i] > cap:
+            groups.append(cur)
+            cur, tot = [], 0
+        cur.append(i)
+        tot += sizes[i]
+    if cur:
+        groups.append(cur)
+    deflate = algorithm in DEFLATE
+    singles = np.zeros(n, dtype=np.int64)
+    pairs = np.zeros((n, n), dtype=np.int64)
+    todo = [(a, b) for a in range(len(groups)) for b in range(a, len(groups))]
+    if show_progress:
+        todo = tqdm(todo)
+    for a, b in todo:
+        members = groups[a] + (groups[b] if b != a else [])
+        ctx.upload_fasta([files[i].absolute() for i in members], reverse_complement=reverse_complement)
+        na = len(groups[a])
+        if b == a:
+            s = ctx.deflate_singles(algorithm) if deflate else ctx.singles()
+            singles[groups[a]] = s.astype(np.int64)
+            ij = [(i, j) for i in range(na) for j in range(na)]
+        else:
+            ij = [(i, na + j) for i in range(na) for j in range(len(groups[b]))]
+            ij += [(j, i) for i, j in ij]
+        got = (ctx.deflate_pairs_list(algorithm, ij) if deflate else ctx.pairs_list(ij)).astype(np.int64)
+        for (i, j), v in zip(ij, got):
+            pairs[members[i], members[j]] = v
+    return singles + GETSIZEOF_OVERHEAD, pairs + GETSIZEOF_OVERHEAD
+
+
 def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directory=None, ctx_factory=None,
                backend="nccl"):
     """Phases A-C for ``-c lz4`` / ``gzip`` / ``zlib`` on the HIP backend.  Returns the float64 NCD
@@ -145,7 +187,18 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
     try:
         # every file is parsed ONCE, by host threads inside the library, then
         # uploaded; phase A (singles + prefix snapshots) runs as part of the upload
-        ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
+        from .hip_backend import ArenaTooBig
+        try:
+            ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
+        except ArenaTooBig:
+            if world > 1:
+                raise
+            if chatty:
+                click.secho("Compressing pairs...", fg="green")
+            singles, pairs = blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress)
+            if save_directory is not None:
+                raise click.ClickException("-s with lz4 needs the whole set in one upload (set too large)")
+            return ncd_matrix(singles, pairs)
         deflate = algorithm in DEFLATE
         singles = (ctx.deflate_singles(algorithm) if deflate else ctx.singles()).astype(np.int64) + GETSIZEOF_OVERHEAD
         if chatty:

@@ -50,6 +50,7 @@ struct snk_ctx_impl {
     bool bytes_legacy = false;      // 1 = linked-mode byte jobs also go to the legacy u32-table kernel
     bool force_generic = false;
     uint32_t header_bytes = 7;
+    uint64_t arena_limit = 0xFFF00000ull;   // arenas are addressed with 32-bit offsets; option arena_limit lowers it (tests)
 
     // resident sequences
     int n = 0, n_packed = 0;
@@ -472,6 +473,9 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         c->fast_waves = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
+    } else if (k == "arena_limit") {
+        if (value < 4096 || (uint64_t)value > 0xFFF00000ull) return fail(c, SNK_E_ARG, "arena_limit must be 4096..0xFFF00000");
+        c->arena_limit = (uint64_t)value;
     } else if (k == "fast_dynamic") {
         if (value < -1 || value > 1) return fail(c, SNK_E_ARG, "fast_dynamic must be -1 (auto), 0 or 1");
         c->fast_dynamic = (int)value;
@@ -554,8 +558,10 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         c->len[g] = (uint32_t)lens[g];
         c->min_len = std::min(c->min_len, c->len[g]); c->max_len = std::max(c->max_len, c->len[g]);
     }
-    if (btot >= 0xFFF00000ull)
-        return fail(c, SNK_E_TOOBIG, "ASCII arena of %zu bytes exceeds the 4 GiB offset range", btot);
+    if (btot >= c->arena_limit)
+        return fail(c, SNK_E_TOOBIG, "ASCII arena of %zu bytes exceeds the %llu-byte offset range of one upload "
+                    "(callers split the matrix into blocks of sequences: snacc_amd.cli.blocked_sizes)", btot,
+                    (unsigned long long)c->arena_limit);
 
     HIPCHK(c, hipMalloc((void **)&c->d_bytes, btot));
     HIPCHK(c, hipMemsetAsync(c->d_bytes, 0, btot, c->stream));
@@ -588,8 +594,8 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
     }
     ptot += SNK_ARENA_SLACK;
-    if (ptot >= 0xFFF00000ull)
-        return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the 4 GiB offset range", ptot);
+    if (ptot >= c->arena_limit)
+        return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the offset range of one upload", ptot);
     HIPCHK(c, hipMalloc((void **)&c->d_packed, ptot));
     HIPCHK(c, hipMemsetAsync(c->d_packed, 0, ptot, c->stream));
     for (size_t g = 0; g < n; ++g) {
@@ -783,7 +789,9 @@ int snk_sync(snk_ctx *c, void *hip_stream)
     if (!c) return SNK_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : c->stream));
-    return check_status(c);
+    int rc = check_status(c);
+    if (rc) return rc;
+    return c->dfl ? snk_internal_dfl_check(c) : SNK_OK;
 }
 
 int snk_pairs(snk_ctx *c, int r0, int r1, uint32_t *sizes)

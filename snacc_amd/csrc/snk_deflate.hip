@@ -68,6 +68,13 @@ struct DflState {
 
 template <typename P> void dfree(P *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
 
+// Temporaries of one build step: freed on every way out of the scope (the early returns of DCHK included).
+struct DevTemps {
+    std::vector<void **> slots;
+    template <typename P> void own(P *&p) { slots.push_back((void **)&p); }
+    ~DevTemps() { for (void **q : slots) if (*q) { (void)hipFree(*q); *q = nullptr; } }
+};
+
 void dfl_destroy(void *v)
 {
     DflState *s = (DflState *)v;
@@ -130,6 +137,29 @@ int dfl_get(snk_ctx *c, SnkSeqView &v, DflState *&s)
     return SNK_OK;
 }
 
+// Tear the add-on's state down (after a failed build): the next call starts from nothing.
+void dfl_drop(snk_ctx *c)
+{
+    void (**free_fn)(void *) = nullptr;
+    void **slot = snk_internal_dfl_slot(c, &free_fn);
+    if (*slot) { dfl_destroy(*slot); *slot = nullptr; }
+}
+
+// Device-side checks of the deflate kernels (DFL_ST_* bits): read, clear, and turn into SNK_E_KERNEL.
+int dfl_check_status(snk_ctx *c, DflState *s)
+{
+    if (!s || !s->d_status) return SNK_OK;
+    uint32_t st = 0;
+    DCHK(c, hipMemcpy(&st, s->d_status, 4, hipMemcpyDeviceToHost));
+    if (st) {
+        (void)hipMemset(s->d_status, 0, 4);
+        char m[128];
+        snprintf(m, sizeof m, "deflate kernel: device-side check failed (status 0x%x: symbol stream beyond its capacity)", st);
+        return snk_internal_fail(c, SNK_E_KERNEL, m);
+    }
+    return SNK_OK;
+}
+
 int dfl_ensure_scratch(snk_ctx *c, DflState *s, size_t njobs)
 {
     if (njobs > s->jobs_cap) {
@@ -181,6 +211,8 @@ int dfl_launch(snk_ctx *c, DflState *s, const SnkSeqView &v, int level, const st
         DCHK(c, hipMemcpyAsync(host_out, s->d_out, jobs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
     }
     DCHK(c, hipStreamSynchronize(v.stream));
+    rc = dfl_check_status(c, s);
+    if (rc != SNK_OK) return rc;
     return dfl_add_elapsed(s);
 }
 
@@ -230,6 +262,7 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
     DCHK(c, hipMemsetAsync(s->d_inv2, 0, itot * 8, v.stream));
 
     uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    DevTemps temps; temps.own(d_key); temps.own(d_skey); temps.own(d_val); temps.own(d_tmp);
     const size_t cap = (size_t)maxlen + 1u;
     DCHK(c, hipMalloc((void **)&d_key, cap * 2));
     DCHK(c, hipMalloc((void **)&d_skey, cap * 2));
@@ -258,8 +291,6 @@ int dfl_build_index(snk_ctx *c, DflState *s, const SnkSeqView &v)
     }
     DCHK(c, hipGetLastError());
     DCHK(c, hipStreamSynchronize(v.stream));
-    dfree(d_key); dfree(d_skey); dfree(d_val);
-    if (d_tmp) (void)hipFree(d_tmp);
     s->indexed = true;
     return SNK_OK;
 }
@@ -277,6 +308,7 @@ int dfl_build_kindex(snk_ctx *c, DflState *s, const SnkSeqView &v)
     DCHK(c, hipMalloc((void **)&s->d_kinv2, itot * 8));
     DCHK(c, hipMalloc((void **)&s->d_kbstart, n * 65537u * 4));
     uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    DevTemps temps; temps.own(d_key); temps.own(d_skey); temps.own(d_val); temps.own(d_tmp);
     const size_t cap = (size_t)maxlen + 1u;
     DCHK(c, hipMalloc((void **)&d_key, cap * 2));
     DCHK(c, hipMalloc((void **)&d_skey, cap * 2));
@@ -306,8 +338,6 @@ int dfl_build_kindex(snk_ctx *c, DflState *s, const SnkSeqView &v)
     }
     DCHK(c, hipGetLastError());
     DCHK(c, hipStreamSynchronize(v.stream));
-    dfree(d_key); dfree(d_skey); dfree(d_val);
-    if (d_tmp) (void)hipFree(d_tmp);
     s->kindexed = true;
     return SNK_OK;
 }
@@ -319,8 +349,13 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     int rc = dfl_get(c, v, s);
     if (rc != SNK_OK) return rc;
     DCHK(c, hipSetDevice(v.device));
-    if (!s->indexed) { rc = dfl_build_index(c, s, v); if (rc != SNK_OK) return rc; }
-    if (level == 9 && v.dfl_kmer && !s->kindexed) { rc = dfl_build_kindex(c, s, v); if (rc != SNK_OK) return rc; }
+    // a build that fails half way (out of memory is the realistic case: ~52 B per base at level 9) is torn
+    // down completely, so that a retry starts from nothing instead of allocating over the old pointers
+    if (!s->indexed) { rc = dfl_build_index(c, s, v); if (rc != SNK_OK) { dfl_drop(c); s = nullptr; return rc; } }
+    if (level == 9 && v.dfl_kmer && !s->kindexed) {
+        rc = dfl_build_kindex(c, s, v);
+        if (rc != SNK_OK) { dfree(s->d_kocc); dfree(s->d_kr3); dfree(s->d_kocc8); dfree(s->d_kinv2); dfree(s->d_kbstart); return rc; }
+    }
     if (s->level == level) return SNK_OK;
     // stand-alone stream of every sequence at this level
     dfree(s->d_chk);
@@ -355,6 +390,7 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
         DCHK(c, hipMalloc((void **)&s->d_seg_pos, aux * 4));
         DCHK(c, hipMalloc((void **)&s->d_seg_cnt, ns * 4));
         DflSeg *d_segs = nullptr; uint32_t *d_from = nullptr, *d_ends = nullptr, *d_fail = nullptr, *d_num = nullptr; uint64_t *d_dst = nullptr;
+        DevTemps temps; temps.own(d_segs); temps.own(d_from); temps.own(d_ends); temps.own(d_fail); temps.own(d_num); temps.own(d_dst);
         DCHK(c, hipMalloc((void **)&d_segs, ns * sizeof(DflSeg)));
         DCHK(c, hipMalloc((void **)&d_from, ns * 4)); DCHK(c, hipMalloc((void **)&d_ends, ns * 4));
         DCHK(c, hipMalloc((void **)&d_fail, ns * 4)); DCHK(c, hipMalloc((void **)&d_num, ns * 4));
@@ -509,7 +545,7 @@ int snk_deflate_pairs(snk_ctx *c, int level, int row_begin, int row_end, uint32_
         DCHK(c, hipStreamSynchronize(v.stream));
         dfl_add_elapsed(s);
     }
-    return SNK_OK;
+    return dfl_check_status(c, s);
 }
 
 /* Same, asynchronous: rows [row_begin, row_end) on `hip_stream` (NULL = the context's stream), u32 raw stream
@@ -559,3 +595,11 @@ double snk_deflate_last_ms(snk_ctx *c)
 }
 
 }  // extern "C"
+
+// snk_sync (snacc_hip.hip) ends with this: the asynchronous deflate launches report through their own status word.
+int snk_internal_dfl_check(snk_ctx *c)
+{
+    void (**free_fn)(void *) = nullptr;
+    void **slot = snk_internal_dfl_slot(c, &free_fn);
+    return *slot ? dfl_check_status(c, (DflState *)*slot) : SNK_OK;
+}

@@ -57,6 +57,7 @@ struct DflSeq {              // one per resident sequence (device + host mirror)
 struct DflJob { int32_t xi, yi; uint32_t mode, out_idx; uint32_t p0, p1; uint64_t aux; };
 constexpr uint32_t DFL_SEG = 32768u;           // segment length of the parallel per-sequence pass
 constexpr uint32_t DFL_SEG_SLACK = 2048u;      // a segment runs this far into the next one, for the stitch
+constexpr uint32_t DFL_ST_CAP = 2u;           // status bit: a stored symbol stream ran beyond its capacity
 constexpr uint32_t DFL_SEG_ROOM = 300u;        // scratch entries beyond that (one match can carry the parser 258 further)
 
 struct DflTables {
@@ -1140,6 +1141,10 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
 #endif
 
     if (lane == 0) {
+        // device-side check (read by dfl_check_status): a stored symbol stream must end inside its capacity --
+        // len + 1 entries for a sequence's own stream, the segment's share of the scratch for a segment job
+        if (w.store && w.nsym > (mode == 2u ? (job.p1 - job.p0) + DFL_SEG_SLACK + DFL_SEG_ROOM : S.lx + S.ly + 1u))
+            atomicOr(T.status, DFL_ST_CAP);
         if (mode == 2u) {
             T.seg_cnt[job.out_idx] = w.nsym;
         } else {

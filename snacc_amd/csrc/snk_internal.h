@@ -23,3 +23,5 @@ int snk_internal_view(snk_ctx *c, SnkSeqView *v);
 int snk_internal_fail(snk_ctx *c, int code, const char *msg);
 // Slot holding the add-on's state; *free_fn is called when the sequences are replaced / the context dies.
 void **snk_internal_dfl_slot(snk_ctx *c, void (***free_fn)(void *));
+// Device-side checks of the deflate kernels since the last call (SNK_OK / SNK_E_KERNEL); defined in snk_deflate.hip.
+int snk_internal_dfl_check(snk_ctx *c);

@@ -35,6 +35,11 @@ class HipBackendError(RuntimeError):
     pass
 
 
+class ArenaTooBig(HipBackendError):
+    """The sequences of one upload exceed the 32-bit offset range of the device arenas (about 4.29 GB of
+    residues): the caller processes the matrix in blocks of sequences (snacc_amd.cli.blocked_sizes)."""
+
+
 _lib = None
 
 
@@ -145,13 +150,15 @@ def _as_u8(seq):
     return np.frombuffer(seq, dtype=np.uint8)
 
 
-E_EMPTY, E_MIXED = -6, -7
+E_TOOBIG, E_EMPTY, E_MIXED = -4, -6, -7
 
 
 def _raise_fasta(L, rc):
     msg = L.snk_fasta_last_error().decode(errors="replace")
     if rc in (E_EMPTY, E_MIXED):
         raise ValueError(msg)              # the reference's / Biopython's exception type
+    if rc == E_TOOBIG and "arena" in msg:
+        raise ArenaTooBig(f"upload failed [{rc}]: {msg}")
     raise HipBackendError(f"FASTA ingest failed [{rc}]: {msg}")
 
 
@@ -191,6 +198,8 @@ class HipContext:
         # SNACC_LZ4_CONTENT_SIZE=1: LZ4 frames carry the 8-byte content-size field (every lz4 size
         # grows by 8, emitted frames get the field).  liblz4's NULL-preferences frame (the default)
         # has none; whether a given py-lz4framed wheel sets it is not knowable offline.
+        if os.environ.get("SNACC_ARENA_LIMIT") and "arena_limit" not in options:      # tests: force the blocked path
+            options = dict(options, arena_limit=int(os.environ["SNACC_ARENA_LIMIT"]))
         if os.environ.get("SNACC_LZ4_CONTENT_SIZE", "0") not in ("", "0"):
             options = dict(content_size=1, **{k: v for k, v in options.items() if k != "content_size"}) \
                 if "content_size" not in options else options
@@ -200,7 +209,8 @@ class HipContext:
     # -- plumbing -----------------------------------------------------------------------
     def _check(self, rc, what):
         if rc != 0:
-            raise HipBackendError(f"{what} failed [{rc}]: {self._L.snk_last_error(self._h).decode()}")
+            err = ArenaTooBig if (rc == E_TOOBIG and "arena" in self._L.snk_last_error(self._h).decode()) else HipBackendError
+            raise err(f"{what} failed [{rc}]: {self._L.snk_last_error(self._h).decode()}")
 
     def close(self):
         if getattr(self, "_h", None):

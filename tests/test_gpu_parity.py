@@ -307,6 +307,36 @@ def test_interleaved_async_launches_and_schedules(hip, oracle_mod):
                 assert np.array_equal(t3.cpu().numpy().view(np.uint32), exp[1:3])
 
 
+def test_sets_beyond_one_upload_are_processed_in_blocks(hip, oracle_mod, tmp_path, monkeypatch):
+    """The device arenas use 32-bit offsets (about 4.29 GB of residues per upload).  A larger set -- here
+    forced by a small arena_limit -- goes through snacc_amd.cli.blocked_sizes: groups of files, every
+    pair of groups uploaded once.  The CSV equals the one-upload run's, for lz4 and gzip."""
+    from click.testing import CliRunner
+    from conftest import write_fasta
+    from snacc_amd import cli as cli_mod
+    d = tmp_path / "fa"
+    d.mkdir()
+    for k in range(7):
+        write_fasta(d / f"g{k}.fasta", [("r", bytes(oracle_mod.lcg_genome(120 + k, 60000 + 17000 * k)).decode())])
+    monkeypatch.chdir(tmp_path)
+    with hip.HipContext(0, arena_limit=200000) as ctx:
+        with pytest.raises(hip.ArenaTooBig):
+            ctx.upload_fasta(sorted(d.iterdir()))
+    for codec in ("lz4", "gzip"):
+        texts = []
+        for limit in (None, "420000"):
+            if limit:
+                monkeypatch.setenv("SNACC_ARENA_LIMIT", limit)
+            else:
+                monkeypatch.delenv("SNACC_ARENA_LIMIT", raising=False)
+            out = tmp_path / f"{codec}_{limit}.csv"
+            res = CliRunner().invoke(cli_mod.cli, [str(d), "-o", str(out), "-c", codec, "--no-show-progress", "--no-log"])
+            assert res.exit_code == 0, (res.output, res.exception)
+            texts.append(out.read_text())
+        assert texts[0] == texts[1], codec
+    monkeypatch.delenv("SNACC_ARENA_LIMIT", raising=False)
+
+
 def test_python_api_single_items(hip, golden):
     """compressed_size(path | (path, path), "lz4") -- the reference's granularity."""
     from pathlib import Path
