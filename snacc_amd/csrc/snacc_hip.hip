@@ -57,7 +57,12 @@ struct snk_ctx_impl {
     uint32_t min_len = 0, max_len = 0;
     std::vector<uint32_t> len;
     std::vector<uint32_t> boff;      // byte offset of every sequence in d_bytes
-    std::vector<uint8_t> is_packed;
+    std::vector<uint8_t> is_packed;  // goes to the 2-bit kernel: pure ACGT, or ACGT with a few exceptions
+    std::vector<uint8_t> has_exc;    // ... the latter
+    bool any_exc = false;
+    long exc_limit = 128;            // flagged 16-base granules per 2^20 bases up to which a sequence stays on the 2-bit kernel
+    uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
+    uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr;
     // deflate add-on (snk_deflate.hip): opaque state + its destructor
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
     bool dfl_serial = false, dfl_kmer = true, dfl_norestart = false;
@@ -101,7 +106,8 @@ void free_sequences(snk_ctx_impl *c)
 {
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
-    dfree(c->d_snap_gen); dfree(c->d_single);
+    dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0;
+    c->has_exc.clear(); c->any_exc = false;
     c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
     if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
     c->dfl = nullptr;
@@ -139,6 +145,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
+    T.exc_flags = c->d_exc_flags; T.exc_off = c->d_exc_off; T.lut_h2s = c->d_lut_h2s; T.lut_s2h = c->d_lut_s2h; T.ovf = c->d_ovf;
     T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
@@ -177,8 +184,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
-        const void *fk = singles ? (const void *)snk_fast_singles_kernel
-                                 : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel;
+        const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
+        const void *fk = exc ? (singles ? (const void *)snk_fastx_singles_kernel
+                                        : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
+                             : (singles ? (const void *)snk_fast_singles_kernel
+                                        : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel);
         HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {   // the kernel addresses its slot LUT at LDS offset 0: that holds only without static LDS
             hipFuncAttributes fa;
@@ -195,7 +205,23 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             G.queue = c->d_queue + (c->queue_next++ & 63u);
             HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.queue, (int)(grid * waves), 1, st));
         }
-        if (singles)
+        if (exc) {
+            const size_t need = (size_t)grid * chains * 4096u * sizeof(uint32_t);       // one overflow table per resident chain
+            if (need > c->ovf_bytes) {
+                HIPCHK(c, hipStreamSynchronize(st));
+                dfree(c->d_ovf);
+                HIPCHK(c, hipMalloc((void **)&c->d_ovf, need));
+                c->ovf_bytes = need;
+                T.ovf = c->d_ovf;
+            }
+        }
+        if (exc && singles)
+            hipLaunchKernelGGL(snk_fastx_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+        else if (exc && c->fast_asm)
+            hipLaunchKernelGGL(snk_fastx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+        else if (exc)
+            hipLaunchKernelGGL(snk_fastx_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+        else if (singles)
             hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (c->fast_asm)
             hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
@@ -438,6 +464,14 @@ int snk_ctx_create(int device, snk_ctx **out)
         CRCHK(hipMalloc((void **)&c->d_hashset, (128 + 256) * sizeof(uint32_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_slot, 1024 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_hash, 1024 * sizeof(uint32_t)));
+        {   // hash <-> slot of the 2-bit table (general path of sequences with exceptions)
+            std::vector<uint16_t> h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);
+            for (uint32_t k = 0; k < 1024; ++k) { h2s[hash[k]] = slot[k]; s2h[slot[k]] = (uint16_t)hash[k]; }
+            CRCHK(hipMalloc((void **)&c->d_lut_h2s, 4096 * sizeof(uint16_t)));
+            CRCHK(hipMalloc((void **)&c->d_lut_s2h, SNK_FSLOTS * sizeof(uint16_t)));
+            CRCHK(hipMemcpy(c->d_lut_h2s, h2s.data(), 8192, hipMemcpyHostToDevice));
+            CRCHK(hipMemcpy(c->d_lut_s2h, s2h.data(), SNK_FSLOTS * 2, hipMemcpyHostToDevice));
+        }
         CRCHK(hipMemcpy(c->d_lut_slot, slot.data(), 2048, hipMemcpyHostToDevice));
         CRCHK(hipMemcpy(c->d_lut_hash, hash.data(), 4096, hipMemcpyHostToDevice));
     }
@@ -452,6 +486,7 @@ void snk_ctx_destroy(snk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_sequences(c);
+    dfree(c->d_lut_h2s); dfree(c->d_lut_s2h);
     dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_lut_h2c4); dfree(c->d_hashset); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
     for (auto &e : c->ev_log) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -473,6 +508,10 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         c->fast_waves = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
+    } else if (k == "exc_limit") {
+        if (c->n) return fail(c, SNK_E_STATE, "exc_limit must be set before snk_upload");
+        if (value < 0 || value > 65536) return fail(c, SNK_E_ARG, "exc_limit must be 0..65536 granules per 2^20 bases");
+        c->exc_limit = value;
     } else if (k == "arena_limit") {
         if (value < 4096 || (uint64_t)value > 0xFFF00000ull) return fail(c, SNK_E_ARG, "arena_limit must be 4096..0xFFF00000");
         c->arena_limit = (uint64_t)value;
@@ -569,30 +608,52 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     for (size_t g = 0; g < n; ++g)
         if (lens[g]) HIPCHK(c, hipMemcpy(c->d_bytes + boff[g], seqs[g], lens[g], hipMemcpyHostToDevice));
 
-    // ---- classify -------------------------------------------------------------------------
-    uint32_t *d_flags = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_flags, n * sizeof(uint32_t)));
-    {
-        std::vector<uint32_t> ones(n, 1u);
-        HIPCHK(c, hipMemcpy(d_flags, ones.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
+    // ---- classify: exception granules -----------------------------------------------------------
+    // A sequence goes to the 2-bit kernel when it is pure upper-case ACGT, or when at most exc_limit of its
+    // 16-base granules per 2^20 bases hold another byte (N runs, IUPAC codes): those few places are served by the
+    // byte-accurate general path of that kernel (snk_fast.hip.h, "Exceptions").
+    std::vector<uint32_t> foff(n, 0), fwords(n, 0);
+    size_t ftot = 0;
+    for (size_t g = 0; g < n; ++g) { fwords[g] = (uint32_t)((((size_t)lens[g] + 15) / 16 + 31) / 32 + 2); foff[g] = (uint32_t)ftot; ftot += fwords[g]; }
+    uint32_t *d_raw = nullptr, *d_cnt = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_raw, std::max<size_t>(ftot, 1) * 4));
+    HIPCHK(c, hipMalloc((void **)&d_cnt, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(d_raw, 0, std::max<size_t>(ftot, 1) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), c->stream));
     for (size_t g = 0; g < n; ++g) {
         if (!lens[g]) continue;
-        uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 1024);
-        hipLaunchKernelGGL(snk_classify_kernel, dim3(grid), dim3(256), 0, c->stream,
-                           c->d_bytes + boff[g], (uint64_t)lens[g], d_flags + g);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(((lens[g] + 15) / 16 + 255) / 256, 1024);
+        hipLaunchKernelGGL(snk_excraw_kernel, dim3(grid), dim3(256), 0, c->stream,
+                           c->d_bytes + boff[g], (uint64_t)lens[g], d_raw + foff[g], d_cnt + g);
     }
-    std::vector<uint32_t> flags(n);
-    HIPCHK(c, hipMemcpyAsync(flags.data(), d_flags, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> ecount(n);
+    HIPCHK(c, hipMemcpyAsync(ecount.data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    dfree(d_flags);
+    dfree(d_cnt);
 
-    // ---- pack pure-ACGT sequences ------------------------------------------------------------
-    c->is_packed.assign(n, 0);
+    // ---- pack ------------------------------------------------------------------------------------
+    c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false;
+    std::vector<uint32_t> eoff(n, 0xFFFFFFFFu);
     for (size_t g = 0; g < n; ++g) {
-        c->is_packed[g] = (flags[g] & 1u) && lens[g] > 0;
+        const uint64_t allowed = 8u + (uint64_t)lens[g] * (uint64_t)c->exc_limit / 1048576u;
+        c->is_packed[g] = lens[g] > 0 && (ecount[g] == 0 || (c->exc_limit > 0 && ecount[g] <= allowed));
+        c->has_exc[g] = c->is_packed[g] && ecount[g] != 0;
+        if (c->has_exc[g]) { c->any_exc = true; eoff[g] = foff[g]; }
         if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
     }
+    HIPCHK(c, hipMalloc((void **)&c->d_exc_off, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy(c->d_exc_off, eoff.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (c->any_exc) {
+        HIPCHK(c, hipMalloc((void **)&c->d_exc_flags, ftot * 4));
+        HIPCHK(c, hipMemsetAsync(c->d_exc_flags, 0, ftot * 4, c->stream));
+        for (size_t g = 0; g < n; ++g)
+            if (c->has_exc[g])
+                hipLaunchKernelGGL(snk_excdilate_kernel, dim3((fwords[g] + 255) / 256), dim3(256), 0, c->stream,
+                                   d_raw + foff[g], fwords[g], c->d_exc_flags + foff[g]);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    dfree(d_raw);
     ptot += SNK_ARENA_SLACK;
     if (ptot >= c->arena_limit)
         return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the offset range of one upload", ptot);
@@ -613,7 +674,10 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         HIPCHK(c, hipMemsetAsync(c->d_hashset, 0, 128 * sizeof(uint32_t), c->stream));
         bool any_packed = false, any_bytes = false;
         for (size_t g = 0; g < n; ++g) {
-            if (c->is_packed[g] && !c->force_generic) { any_packed = true; continue; }   // contributes the 894 ACGT hashes
+            if (c->is_packed[g] && !c->force_generic) {
+                any_packed = true;                                   // contributes the 894 ACGT hashes
+                if (!c->has_exc[g]) continue;                        // ... and, with exceptions, the hashes of those places
+            }
             if (lens[g] < 5) continue;
             any_bytes = true;
             uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 1024);
@@ -712,7 +776,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     for (size_t g = 0; g < n; ++g) {
         SnkJob jb; jb.xi = (int)g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
         const bool f = !c->force_generic && c->is_packed[g] && lens[g] > SNK_BLOCK;
-        if (f) { fast.push_back(jb); conv.push_back((uint32_t)g); }
+        if (f) { fast.push_back(jb); if (!c->any_exc) conv.push_back((uint32_t)g); }     // (the fastx kernel dumps snap_gen itself)
         else if (lens[g] > SNK_BLOCK && !c->bytes_legacy) bytes.push_back(jb);
         else gen.push_back(jb);
     }

@@ -73,6 +73,12 @@ struct SnkTables {
     const uint16_t *lut_h2c;          // [4096]  compact byte kernel: hash -> slot 0..CAP-1, 0xFFFF = not in the resident set
     const uint16_t *lut_h2c4;         // [8192]  the same for the one-shot hash of 4 bytes
     const uint8_t  *zero_pad;         // >= 2*SNK_PAD zero bytes
+    // 2-bit kernel on sequences with a few non-ACGT bytes ("exceptions": N runs, IUPAC codes; snk_fast.hip.h)
+    const uint32_t *exc_flags;        // 1 bit per 16 bases: an exception lies within bases [16g - 16, 16g + 32)
+    const uint32_t *exc_off;          // per sequence: its first word in exc_flags, 0xFFFFFFFF = the sequence has none
+    const uint16_t *lut_h2s;          // [4096] liblz4 hash of 5 bytes -> slot of the 2-bit table, 0xFFFF = no ACGT 5-mer has it
+    const uint16_t *lut_s2h;          // [896]  slot -> hash
+    uint32_t       *ovf;              // [resident chains][4096] overflow tables (absolute positions, liblz4's own layout)
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };
 
@@ -99,6 +105,42 @@ __device__ __forceinline__ uint64_t snk_ld8g(snk_g8 *p)
 __device__ __forceinline__ uint32_t snk_ld4g(snk_g8 *p)
 {
     return ((SNK_AS1 const SnkU32 *)p)->v;   // byte-aligned 4-byte load
+}
+
+// ---- byte-accurate view of the concatenation x+y (legacy byte kernel, frame emission, and the 2-bit
+// kernel's general path for sequences with exceptions) ----
+struct SnkGenSrc {
+    const uint8_t *xb, *yb;
+    uint32_t lx;
+};
+
+__device__ __forceinline__ uint32_t snk_byte_at(const SnkGenSrc &s, uint32_t p)
+{
+    return p < s.lx ? s.xb[p] : s.yb[p - s.lx];
+}
+
+__device__ __forceinline__ uint64_t snk_ld8_straddle(const SnkGenSrc &s, uint32_t p)
+{
+    uint64_t v = 0;
+    for (uint32_t b = 0; b < 8u; ++b) v |= (uint64_t)snk_byte_at(s, p + b) << (8u * b);
+    return v;
+}
+
+// 8 bytes of the concatenation starting at p (bytes past the end read as padding)
+__device__ __forceinline__ uint64_t snk_ld8(const SnkGenSrc &s, uint32_t p)
+{
+    if (__builtin_expect(p + 8u <= s.lx, 1)) return snk_ld8u(s.xb + p);
+    if (p >= s.lx) return snk_ld8u(s.yb + (p - s.lx));
+    return snk_ld8_straddle(s, p);
+}
+
+__device__ __forceinline__ uint32_t snk_hash5(uint64_t v)
+{
+    return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
+}
+__device__ __forceinline__ uint32_t snk_hash4(uint64_t v)
+{
+    return ((uint32_t)v * 2654435761u) >> 19;
 }
 
 // Diagnostic trace (only with -DSNK_TRACE, `make trace`; never shipped): lane 0 of workgroup 0

@@ -94,10 +94,151 @@ struct SnkFastLane {
     uint32_t endcode;                      // 0 running, 1 ends with last-literals, 2 liblz4 gave up (raw)
     bool pending;                          // put(cur-2) owed before the next probe
     SnkWin w;
+    // ---- only used by the instantiations for sequences with exceptions (EXC) ----
+    SnkGenSrc g;                           // the ASCII bytes of x and y
+    const uint32_t *fx, *fy;               // dilated exception flags of x / y (NULL: none)
+    uint32_t *ovf;                         // this chain's overflow table
+    uint32_t xlim;                         // first position >= the last scan whose window is not clean
 };
+
+// =========================================================================
+//  Exceptions: a few non-ACGT bytes in an otherwise 2-bit sequence
+// =========================================================================
+// A position p is CLEAN when its window [p-4, p+12) lies inside one sequence, >= 4 bases from the
+// stream start, and its 16-base granule is not flagged (no exception within the window, by the
+// dilation of the flags).  The steady loop only ever probes and inserts clean positions: 5-mer,
+// hash and the 2-bit compare are then exactly what liblz4 sees on the bytes.  Everything else goes
+// through the byte-accurate general path below: hash of the real 5 bytes; if an ACGT 5-mer has
+// that hash the slot of the 2-bit table is used -- with the offset when the inserted position is
+// clean, else with the sentinel 0xFFFF and the absolute position in the chain's overflow table
+// ovf[hash] -- otherwise only ovf[hash] (liblz4's own table restricted to the non-ACGT hashes).
+// A steady-loop probe that reads a sentinel leaves through the service exit; aging treats a
+// sentinel like any other entry (an entry older than one block is dead whatever it points to).
+__device__ __forceinline__ bool snk_exc_clean(const SnkFastLane &L, uint32_t p)
+{
+    const uint32_t lx = L.s.lx;
+    if (p + 12u <= lx) {                                        // (p < 4: the bases before the stream start are zero padding,
+        if (!L.fx) return true;                                 //  and the steady loop never extends a match back beyond position 0)
+        const uint32_t g = p < 4u ? 0u : (p - 4u) >> 4;
+        return ((L.fx[g >> 5] >> (g & 31u)) & 1u) == 0u;
+    }
+    if (p >= lx + 4u) {
+        if (!L.fy) return true;
+        const uint32_t g = (p - 4u - lx) >> 4;
+        return ((L.fy[g >> 5] >> (g & 31u)) & 1u) == 0u;
+    }
+    return false;                                               // the window straddles the seam
+}
+
+// first flagged granule in [g, gend], or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t snk_exc_scan(const uint32_t *f, uint32_t g, uint32_t gend)
+{
+    while (g <= gend) {
+        const uint32_t w = f[g >> 5] >> (g & 31u);
+        if (w) {
+            const uint32_t gf = g + (uint32_t)__builtin_ctz(w);
+            return gf <= gend ? gf : 0xFFFFFFFFu;
+        }
+        g = (g | 31u) + 1u;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// first position p' >= p that is not clean (0xFFFFFFFF: none)
+__device__ __forceinline__ uint32_t snk_exc_next(const SnkFastLane &L, uint32_t p)
+{
+    const uint32_t lx = L.s.lx;
+    if (p + 12u <= lx) {
+        const uint32_t stop = lx - 11u;                         // the seam gap at the latest
+        if (!L.fx) return stop;
+        const uint32_t gf = snk_exc_scan(L.fx, p < 4u ? 0u : (p - 4u) >> 4, stop < 5u ? 0u : (stop - 5u) >> 4);
+        if (gf == 0xFFFFFFFFu) return stop;
+        const uint32_t q = 16u * gf + 4u;
+        return q > p ? q : p;
+    }
+    if (p < lx + 4u) return p;
+    if (!L.fy) return 0xFFFFFFFFu;
+    const uint32_t gf = snk_exc_scan(L.fy, (p - 4u - lx) >> 4, (L.n - lx) >> 4);
+    if (gf == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+    const uint32_t q = lx + 16u * gf + 4u;
+    return q > p ? q : p;
+}
+
+__device__ __forceinline__ void snk_exc_put(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm, uint32_t h, uint32_t pos)
+{
+    const uint32_t s = T.lut_h2s[h];
+    if (s != 0xFFFFu) {
+        const bool cl = snk_exc_clean(L, pos);
+        tbl[s] = cl ? (uint16_t)(pos - L.base) : (uint16_t)0xFFFFu;
+        atomicOr(&bm[s >> 5], 1u << (s & 31u));
+        if (!cl) L.ovf[h] = pos;
+    } else {
+        L.ovf[h] = pos;
+    }
+}
+
+__device__ __forceinline__ uint32_t snk_exc_get(const SnkFastLane &L, const SnkTables &T, const uint16_t *tbl, const uint32_t *bm,
+                                                uint32_t h, uint32_t cur, bool &valid)
+{
+    const uint32_t s = T.lut_h2s[h];
+    if (s != 0xFFFFu) {
+        const uint32_t e = tbl[s];
+        if (e != 0xFFFFu) {
+            const bool iscur = ((bm[s >> 5] >> (s & 31u)) & 1u) != 0u;
+            valid = iscur | (e > cur - L.base);
+            return L.base + e - (iscur ? 0u : 65536u);
+        }
+    }
+    const uint32_t cand = L.ovf[h];
+    valid = cand + SNK_MAXDIST >= cur;
+    return cand;
+}
+
+// liblz4's match accounting on the real bytes (cf. snk_fast_match_slow, which does it on 2-bit windows)
+__device__ __forceinline__ void snk_exc_match(SnkFastLane &L, uint32_t cur, uint32_t cand)
+{
+    const SnkGenSrc &g = L.g;
+    uint32_t ip = cur;
+    while (ip > L.anchor && cand > 0u && snk_byte_at(g, ip - 1u) == snk_byte_at(g, cand - 1u)) { ip--; cand--; }
+    const uint32_t lit = ip - L.anchor;
+    uint32_t op = L.op + 1u;
+    bool bail = op + lit + 8u + lit / 255u > L.olimit;
+    uint32_t a = ip + 4u;
+    if (!bail) {
+        op += lit + snk_lit_ext(lit) + 2u;
+        uint32_t b = cand + 4u;
+        while (a < L.mlimit) {
+            const uint64_t d = snk_ld8(g, a) ^ snk_ld8(g, b);
+            if (d) { a += (uint32_t)__builtin_ctzll(d) >> 3; break; }
+            a += 8u; b += 8u;
+        }
+        if (a > L.mlimit) a = L.mlimit;
+        const uint32_t mc = a - (ip + 4u);
+        bail = op + 6u + (mc + 240u) / 255u > L.olimit;
+        if (mc >= 15u) op += (mc - 15u) / 255u + 1u;
+    }
+    if (bail) { L.endcode = 2u; L.mfl1 = 0u; L.step = 1u; L.cur = cur; return; }
+    L.op = op; L.anchor = a;
+    L.cur = a; L.step = 1u; L.nb = 63u; L.pending = true;
+    if (a >= L.mfl1) { L.endcode = 1u; L.mfl1 = 0u; }
+}
+
+// the byte-accurate counterpart of snk_fast_finish
+__device__ __forceinline__ void snk_exc_finish(SnkFastLane &L, uint32_t cur, uint32_t cand, bool valid)
+{
+    const uint64_t wc = snk_ld8(L.g, cur);
+    const uint64_t wd = snk_ld8(L.g, valid ? cand : cur);
+    if (valid & ((uint32_t)wc == (uint32_t)wd)) {
+        snk_exc_match(L, cur, cand);
+    } else {
+        const uint32_t s3 = L.nb >> 6;
+        L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
+    }
+}
 
 // Rare path (once per 64 KiB): close the finished block, age the table, open the next block.
 // Returns true when the frame is complete (size written).
+template <bool EXC>
 __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                  const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
@@ -118,8 +259,18 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
         if (L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
             // prefix snapshot: absolute positions; entries older than one block -> 0 (too far for good)
             uint32_t *dst = T.snap_fast + (size_t)L.xi * SNK_FSLOTS;
-            for (uint32_t t = 0; t < SNK_FSLOTS; ++t)
-                dst[t] = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.base + tbl[t]) : 0u;
+            for (uint32_t t = 0; t < SNK_FSLOTS; ++t) {
+                uint32_t v = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.base + tbl[t]) : 0u;
+                if (EXC && v != 0u && tbl[t] == 0xFFFFu) v = t < 894u ? L.ovf[T.lut_s2h[t]] : 0u;   // sentinel: the position is in the overflow table
+                dst[t] = v;
+            }
+            if (EXC) {      // liblz4's whole table (what a byte kernel, or another chain with exceptions, starts from)
+                uint32_t *gen = T.snap_gen + (size_t)L.xi * 4096u;
+                for (uint32_t h = 0; h < 4096u; ++h) {
+                    const uint32_t sl = T.lut_h2s[h];
+                    gen[h] = sl != 0xFFFFu ? dst[sl] : L.ovf[h];
+                }
+            }
             T.snap_out[L.xi] = L.total;
         }
         if (L.pos >= L.n) { out[L.out_idx] = L.total + 4u; return true; }      // + end mark
@@ -146,7 +297,9 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
         L.first = false;
         L.base = L.pos - L.k3;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
-        {
+        if (EXC) {
+            snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, L.pos)), L.pos);
+        } else {
             const uint32_t w0 = snk_fetch32(L.s, L.pos);
             const uint32_t s0 = slot[(w0 >> 8) & 1023u];
             tbl[s0] = (uint16_t)L.k3;                                 // the block start, relative to the virtual base
@@ -214,12 +367,22 @@ __device__ __forceinline__ void snk_fast_finish(SnkFastLane &L, uint32_t cur, ui
 // One probe the general way (any source, any state): opens and closes blocks, walks the seam and
 // the stream start, serves lanes the steady loop has handed over.  Returns true when the lane's
 // frame is complete.  Rare path: block edges, seams, service -- speed is irrelevant here.
+template <bool EXC>
 __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                               const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur;
     if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
-        return snk_fast_block_step(L, T, tbl, bm, slot, out, status);
+        return snk_fast_block_step<EXC>(L, T, tbl, bm, slot, out, status);
+    if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
+        if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
+        const uint32_t h = snk_hash5(snk_ld8(L.g, cur));
+        bool valid;
+        const uint32_t cand = snk_exc_get(L, T, tbl, bm, h, cur, valid);
+        snk_exc_put(L, T, tbl, bm, h, cur);
+        snk_exc_finish(L, cur, cand, valid);
+        return false;
+    }
     const uint32_t wc = snk_fetch32(L.s, cur);
     const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
     uint32_t s2 = slot[(wc >> 4) & 1023u];                   // slot of the 5-mer at cur-2
@@ -349,6 +512,16 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_cmp_gt_u32_e32 vcc, 15, v100\n\t" \
     "s_and_b64 %[ss], vcc, %[sv]\n\t" \
     "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
+// instantiations for sequences with exceptions: a table entry 0xFFFF (v91) is a sentinel -- the position is in
+// the chain's overflow table -- and trips the limit test like a straddling window
+#define SNK_STEADY_SENTINEL_DUAL \
+    "v_cmp_eq_u32_e32 vcc, 0xffff, v91\n\t" \
+    "s_or_b64 %[ss], %[ss], vcc\n\t" \
+    "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
+#define SNK_STEADY_SENTINEL_YONLY \
+    "v_cmp_eq_u32_e32 vcc, 0xffff, v91\n\t" \
+    "s_mov_b64 %[ss], vcc\n\t" \
+    "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
 // compare, next cursor, next window + LUT reads, accounting, exit test (LIM = limit register)
 #define SNK_STEADY_REST(LIM) \
     "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
@@ -405,11 +578,12 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 // ranges, cursor served by the reservoir's source.
 #define SNK_FAST_MAXLIT   15u      // the steady loop leaves at literal runs >= 15 (length-extension bytes)
 #define SNK_FAST_ZONE     80u      // ... and when op comes within 80 bytes of the block's output budget
+template <bool EXC>
 __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 {
     const uint32_t o = L.cur - 4u - L.w.rb;
     return (L.cur + L.step <= L.mfl1) & (L.step == 1u) & (L.nb < 63u + SNK_FAST_MAXLIT) &
-           (L.op + SNK_FAST_ZONE <= L.olimit) & (o < 32u) & (L.cur <= L.w.lim);
+           (L.op + SNK_FAST_ZONE <= L.olimit) & (o < 32u) & (L.cur <= L.w.lim) & (!EXC || L.cur < L.xlim);
 }
 
 // The steady loop: one probe per trip for every lane of the wave, no divergent branch, ONE
@@ -432,7 +606,7 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 //
 // ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
-template <bool ASM>
+template <bool ASM, bool EXC>
 __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off)
 {
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
@@ -449,7 +623,9 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     const uint32_t xoffB = L.s.xoff + (uint32_t)(X0 >> 2), yoffB = L.s.yoff + (uint32_t)(Y0 >> 2);
     const int32_t sx = (int32_t)L.s.lx - 11 - T0;                 // t < sx: window inside x; t >= sx + 15: inside y
     const uint32_t limw = w.lim == 0xFFFFFFFFu ? w.lim : w.lim + 1u;
-    const uint32_t limc = (L.mfl1 < limw ? L.mfl1 : limw) - vb;   // next probe position >= limc: service
+    uint32_t lim_abs = L.mfl1 < limw ? L.mfl1 : limw;
+    if (EXC) lim_abs = lim_abs < L.xlim ? lim_abs : L.xlim;       // ... the cursor window must stay clean
+    const uint32_t limc = lim_abs - vb;                           // next probe position >= limc: service
     const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
 
     uint32_t c = L.cur - vb, anchor_c = L.anchor - vb, op = L.op;
@@ -477,12 +653,21 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
         // every lane's block wholly > 64 KiB past its seam (no t can land in x or on the seam)?
-        if (__all(sx + 15 <= 0))
-            asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
-                         SNK_STEADY_OPERANDS);
-        else
-            asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW("v103") SNK_STEADY_STRADDLE SNK_STEADY_REST("v105")
-                         SNK_STEADY_OPERANDS);
+        if (!EXC) {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
+                             SNK_STEADY_OPERANDS);
+            else
+                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW("v103") SNK_STEADY_STRADDLE SNK_STEADY_REST("v105")
+                             SNK_STEADY_OPERANDS);
+        } else {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_SENTINEL_YONLY SNK_STEADY_REST("v105")
+                             SNK_STEADY_OPERANDS);
+            else
+                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW("v103") SNK_STEADY_STRADDLE SNK_STEADY_SENTINEL_DUAL
+                             SNK_STEADY_REST("v105") SNK_STEADY_OPERANDS);
+        }
         c = lit + anchor_c;                                           // the loop keeps the NEXT cursor in c
         valid = t > c;
     } else
@@ -531,7 +716,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         // service: literal run >= 15, back-extension reaches 4 (may go on), output budget near
         int32_t mx = (int32_t)(b + 11u) > (int32_t)lit ? (int32_t)(b + 11u) : (int32_t)lit;
         { const int32_t z = (int32_t)op - olimZ + 14; mx = mx > z ? mx : z; }       // op before this probe > olimit - 70
-        const bool svc = (mx >= 15) | (ncur >= limc) | straddle;
+        const bool svc = (mx >= 15) | (ncur >= limc) | straddle | (EXC && e == 0xFFFFu);       // sentinel: position in the overflow table
         SNK_TRACE_REC(3u, vb + c, (uint32_t)(T0 + (int32_t)t), (r << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), vb + c);
         if (__builtin_amdgcn_ballot_w64(svc) != 0ull) break;
 
@@ -543,7 +728,17 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     // hand every lane over in the state "table operations of the probe at c done, match not evaluated"
     L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
     w.rb = 0x80000000u;                                           // reservoir not kept: the head re-seats it
-    snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+    if (EXC) {
+        // (T is not needed: the hash comes from the bytes, the overflow table is the lane's)
+        uint32_t cand = (uint32_t)(T0 + (int32_t)t);
+        if ((t & 0xFFFFu) == 0xFFFFu) {                           // sentinel read: the candidate is in the overflow table
+            cand = L.ovf[snk_hash5(snk_ld8(L.g, vb + c))];
+            valid = cand + SNK_MAXDIST >= vb + c;
+        }
+        snk_exc_finish(L, vb + c, cand, valid);
+    } else {
+        snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+    }
 }
 
 // How job numbers map to ordered pairs, and how the waves of a launch share them.
@@ -602,7 +797,7 @@ __device__ __forceinline__ void snk_fast_lane_init(SnkFastLane &L, const SnkTabl
 // Every wave runs ONE flat loop: hand jobs to lanes that have none, general probes until every
 // working lane is eligible, steady loop until some lane needs service.  The wave leaves when its
 // lanes are idle and no job is left.
-template <bool ASM>
+template <bool ASM, bool EXC>
 __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkFastGrid &G,
                                                      uint32_t lanes, uint32_t *out, uint32_t *status)
 {
@@ -670,20 +865,48 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                 // offsets from the virtual base of the block before spos (k3 = -lx mod 4, see snk_fast_steady)
                 const uint32_t k3 = (0u - T.len[xi]) & 3u;
                 const uint32_t pvb = spos - 65536u - k3;
+                // (EXC) a snapshot position whose window is not clean gets the sentinel: the chain's overflow table,
+                // filled from the sequence's full snapshot below, holds it
+                const uint32_t xlen = T.len[xi];
+                const uint32_t *xfl = (EXC && T.exc_off[xi] != 0xFFFFFFFFu) ? T.exc_flags + T.exc_off[xi] : nullptr;
                 for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
                     uint32_t v = k3 * 0x10001u;                       // stream start: every slot holds position 0
                     if (use) {
                         const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
-                        const uint32_t lo = (a0 != 0u && a0 + 65536u >= spos) ? a0 - pvb : 0u;   // previous block, else dead
-                        const uint32_t hi = (a1 != 0u && a1 + 65536u >= spos) ? a1 - pvb : 0u;
+                        uint32_t lo = (a0 != 0u && a0 + 65536u >= spos) ? a0 - pvb : 0u;   // previous block, else dead
+                        uint32_t hi = (a1 != 0u && a1 + 65536u >= spos) ? a1 - pvb : 0u;
+                        if (EXC) {
+                            // (snapshot positions are >= spos - 65536 >= 0 and inside x; a0 >= 4 unless the stream is young)
+                            const uint32_t g0 = a0 < 4u ? 0u : (a0 - 4u) >> 4, g1 = a1 < 4u ? 0u : (a1 - 4u) >> 4;
+                            if (lo && !(a0 + 12u <= xlen && !(xfl && ((xfl[g0 >> 5] >> (g0 & 31u)) & 1u)))) lo = 0xFFFFu;
+                            if (hi && !(a1 + 12u <= xlen && !(xfl && ((xfl[g1 >> 5] >> (g1 & 31u)) & 1u)))) hi = 0xFFFFu;
+                        }
                         v = lo | (hi << 16);
+                    } else if (EXC && (xlen < 12u || (xfl && (xfl[0] & 1u)))) {
+                        v = 0xFFFFFFFFu;                              // position 0 is not clean: sentinel, the overflow table (all zero) holds it
                     }
                     ((uint32_t *)dst)[t] = v;
+                }
+                if (EXC) {
+                    uint32_t *ov = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + l) * 4096u;
+                    const uint32_t *gsrc = T.snap_gen + (size_t)xi * 4096u;
+                    for (uint32_t t = lane; t < 4096u; t += SNK_COOP(64u)) ov[t] = use ? gsrc[t] : 0u;
                 }
                 // no snapshot: position 0 counts as "written in this block"
                 for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;
             }
-            if (take) { snk_fast_lane_init(L, T, job); have = true; need = false; parked = false; }
+            if (take) {
+                snk_fast_lane_init(L, T, job); have = true; need = false; parked = false;
+                if (EXC) {
+                    L.g.xb = T.bytes_arena + T.bytes_off[job.xi];
+                    L.g.yb = job.yi >= 0 ? T.bytes_arena + T.bytes_off[job.yi] : T.zero_pad + SNK_PAD;
+                    L.g.lx = L.s.lx;
+                    L.fx = T.exc_off[job.xi] != 0xFFFFFFFFu ? T.exc_flags + T.exc_off[job.xi] : nullptr;
+                    L.fy = (job.yi >= 0 && T.exc_off[job.yi] != 0xFFFFFFFFu) ? T.exc_flags + T.exc_off[job.yi] : nullptr;
+                    L.ovf = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + lane) * 4096u;
+                    L.xlim = 0u;
+                }
+            }
             const uint32_t asked = (uint32_t)__builtin_popcountll(mask);
             wb += asked < avail ? asked : avail;
         }
@@ -697,22 +920,24 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
             // more: the wave then walks y as one band of a few KB and the L1 keeps serving the windows.
             const bool anyx = __any(have && L.cur < L.s.lx + 4u);      // wave-uniform: some lane is still inside its x
             if (!anyx) parked = false;
-            bool ok = !have || parked || snk_fast_eligible(L);
+            if (EXC && have && L.cur >= L.xlim && L.cur + L.step <= L.mfl1)
+                L.xlim = snk_exc_next(L, L.cur);             // (the cursor itself when its window is not clean)
+            bool ok = !have || parked || snk_fast_eligible<EXC>(L);
             if (!ok && L.cur + L.step <= L.mfl1) {           // inside a block: can the reservoir be re-seated?
                 const uint32_t cur = L.cur, lx = L.s.lx;
                 if (cur >= lx + 4u) {
                     if (L.w.org != lx && anyx) parked = true;                 // first time on y
                     snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
                 } else if (cur >= 4u && cur + 12u <= lx)   snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
-                ok = parked || snk_fast_eligible(L);
+                ok = parked || snk_fast_eligible<EXC>(L);
             }
             if (__builtin_expect(!__any(!ok), 1)) break;
-            if (!ok && snk_fast_iter(L, T, tbl, bm, slot, out, status)) have = false;        // frame complete
+            if (!ok && snk_fast_iter<EXC>(L, T, tbl, bm, slot, out, status)) have = false;   // frame complete
             if (!dry && __any(lane_on && !have)) { refill = true; break; }
         }
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
-        if (have && !parked) snk_fast_steady<ASM>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off);
+        if (have && !parked) snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off);
     }
 }
 
@@ -720,20 +945,34 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 // phase B: ordered pairs (the dominant kernel of the bench)
 __global__ void snk_fast_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body<true>(T, G, lanes, out, status);
+    snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
 }
 
 // the same with the C++ statement of the steady loop (option fast_asm = 0: cross-check of the
 // hand-scheduled loop in the tests, A/B timing)
 __global__ void snk_fast_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body<false>(T, G, lanes, out, status);
+    snk_fast_kernel_body<false, false>(T, G, lanes, out, status);
 }
 
 // phase A: single sequences + prefix snapshots at upload (same code, own symbol so that profiles
 // keep the two phases apart)
 __global__ void snk_fast_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    snk_fast_kernel_body<true>(T, G, lanes, out, status);
+    snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
+}
+
+// the three again for resident sets in which some 2-bit sequence has exceptions (N runs, IUPAC codes)
+__global__ void snk_fastx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fast_kernel_body<true, true>(T, G, lanes, out, status);
+}
+__global__ void snk_fastx_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fast_kernel_body<false, true>(T, G, lanes, out, status);
+}
+__global__ void snk_fastx_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fast_kernel_body<true, true>(T, G, lanes, out, status);
 }
 #endif

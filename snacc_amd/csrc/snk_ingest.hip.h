@@ -22,6 +22,36 @@ __global__ void snk_classify_kernel(const uint8_t *bytes, uint64_t n, uint32_t *
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, ~1u);
 }
 
+// Exception granules (2-bit kernel on sequences with a few non-ACGT bytes, snk_fast.hip.h): one thread per
+// 16-base granule; raw[g] is set when the granule holds a byte outside {A,C,G,T}; *count += flagged granules.
+__global__ void snk_excraw_kernel(const uint8_t *bytes, uint64_t n, uint32_t *raw, uint32_t *count)
+{
+    const uint64_t ngran = (n + 15u) >> 4;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t mine = 0;
+    for (; g < ngran; g += stride) {
+        bool bad = false;
+        for (uint32_t b = 0; b < 16u; ++b) {
+            const uint64_t i = g * 16u + b;
+            if (i < n) { const uint8_t c = bytes[i]; bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+        }
+        if (bad) { atomicOr(&raw[g >> 5], 1u << (g & 31u)); mine++; }
+    }
+    if (mine) atomicAdd(count, mine);
+}
+
+// Dilation by one granule either side: out bit g = raw bit g-1 | g | g+1, i.e. "an exception lies within
+// bases [16g - 16, 16g + 32)" -- any 16-base window that starts in granule g is then covered by bit g alone.
+__global__ void snk_excdilate_kernel(const uint32_t *raw, uint32_t nwords, uint32_t *out)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const uint32_t v = raw[w];
+    const uint32_t lo = w ? raw[w - 1u] >> 31 : 0u, hi = w + 1u < nwords ? raw[w + 1u] << 31 : 0u;
+    out[w] = v | (v << 1) | (v >> 1) | lo | hi;
+}
+
 // 2-bit pack: code = (c >> 1) & 3  (A=0, C=1, T=2, G=3); one output byte per thread.
 __global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packed)
 {

@@ -7,39 +7,7 @@
 //  generic byte kernel
 // =========================================================================
 
-struct SnkGenSrc {
-    const uint8_t *xb, *yb;
-    uint32_t lx;
-};
-
-__device__ __forceinline__ uint32_t snk_byte_at(const SnkGenSrc &s, uint32_t p)
-{
-    return p < s.lx ? s.xb[p] : s.yb[p - s.lx];
-}
-
-__device__ __forceinline__ uint64_t snk_ld8_straddle(const SnkGenSrc &s, uint32_t p)
-{
-    uint64_t v = 0;
-    for (uint32_t b = 0; b < 8u; ++b) v |= (uint64_t)snk_byte_at(s, p + b) << (8u * b);
-    return v;
-}
-
-// 8 bytes of the concatenation starting at p (bytes past the end read as padding)
-__device__ __forceinline__ uint64_t snk_ld8(const SnkGenSrc &s, uint32_t p)
-{
-    if (__builtin_expect(p + 8u <= s.lx, 1)) return snk_ld8u(s.xb + p);
-    if (p >= s.lx) return snk_ld8u(s.yb + (p - s.lx));
-    return snk_ld8_straddle(s, p);
-}
-
-__device__ __forceinline__ uint32_t snk_hash5(uint64_t v)
-{
-    return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
-}
-__device__ __forceinline__ uint32_t snk_hash4(uint64_t v)
-{
-    return ((uint32_t)v * 2654435761u) >> 19;
-}
+// (SnkGenSrc, snk_byte_at, snk_ld8, snk_hash5, snk_hash4: snk_common.hip.h)
 
 template <bool LINKED>
 __device__ __forceinline__ uint32_t snk_tget(const uint32_t *t32, uint32_t h)

@@ -1,6 +1,7 @@
 // fast_emu.cpp -- TEST INFRASTRUCTURE.  Runs the 2-bit kernel's source (snk_fast.hip.h) on the CPU,
 // one lane at a time (snk_host_emu.h), over the same HBM layout snk_upload builds: packed arena,
-// 5-mer -> slot LUT, prefix snapshots from the singles pass, then the ordered pairs.
+// ASCII arena, 5-mer -> slot LUT, exception flags, prefix snapshots from the singles pass, then the
+// ordered pairs.  Sequences with a few non-ACGT bytes run the instantiation for exceptions (EXC).
 // Build: g++ -O1 -DSNK_HOST_EMU -I tests/emu -I snacc_amd/csrc -shared -fPIC -o tests/emu/libfast_emu.so tests/emu/fast_emu.cpp
 #include "snk_fast.hip.h"
 #include <vector>
@@ -14,13 +15,17 @@ uint32_t host_hash5(const uint8_t *p)
     return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
 }
 
+bool acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
 } // namespace
 
+// exc_limit: flagged 16-base granules per 2^20 bases (+8) up to which a sequence with non-ACGT bytes stays on
+// the 2-bit kernel (0: pure ACGT only).  Entries of `singles` / `pairs` that the kernel does not serve stay 0.
 extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t *lens,
-                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes)
+                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit)
 {
     const char code2byte[4] = { 'A', 'C', 'T', 'G' };
-    std::vector<uint16_t> slot(1024, 0);
+    std::vector<uint16_t> slot(1024, 0), h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);
     {
         std::vector<int> slot_of_hash(4096, -1);
         int n_slots = 0;
@@ -30,37 +35,64 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
             const uint32_t h = host_hash5(b);
             if (slot_of_hash[h] < 0) slot_of_hash[h] = n_slots++;
             slot[k] = (uint16_t)slot_of_hash[h];
+            h2s[h] = slot[k]; s2h[slot[k]] = (uint16_t)h;
         }
         if (n_slots > (int)SNK_FSLOTS) return -1;
     }
-    std::vector<uint8_t> ok((size_t)n, 0);
-    std::vector<uint32_t> poff((size_t)n, 0), len((size_t)n), spos((size_t)n);
-    size_t ptot = SNK_ARENA_SLACK;
+    std::vector<uint8_t> ok((size_t)n, 0), exc((size_t)n, 0);
+    std::vector<uint32_t> poff((size_t)n, 0), boff((size_t)n, 0), len((size_t)n), spos((size_t)n), eoff((size_t)n, 0xFFFFFFFFu);
+    std::vector<std::vector<uint32_t>> flags((size_t)n);
+    size_t ptot = SNK_ARENA_SLACK, btot = SNK_PAD, ftot = 0;
+    bool any_exc = false;
     for (int g = 0; g < n; ++g) {
         len[g] = (uint32_t)lens[g];
-        bool pure = lens[g] > 0;
-        for (uint64_t i = 0; i < lens[g]; ++i) {
-            const uint8_t c = seqs[g][i];
-            pure &= (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        boff[g] = (uint32_t)btot; btot += ((size_t)lens[g] + 63) / 64 * 64 + SNK_PAD;
+        // raw flags per 16-base granule, then the dilation (as snk_excraw_kernel / snk_excdilate_kernel)
+        const size_t ngran = ((size_t)lens[g] + 15) / 16, nwords = (ngran + 31) / 32 + 2;
+        std::vector<uint32_t> raw(nwords, 0);
+        uint32_t cnt = 0;
+        for (size_t q = 0; q < ngran; ++q) {
+            bool bad = false;
+            for (size_t i = q * 16; i < q * 16 + 16 && i < lens[g]; ++i) bad |= !acgt(seqs[g][i]);
+            if (bad) { raw[q >> 5] |= 1u << (q & 31); cnt++; }
         }
-        ok[g] = pure;
-        if (pure) { poff[g] = (uint32_t)ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; }
+        flags[g].assign(nwords, 0);
+        for (size_t w = 0; w < nwords; ++w) {
+            const uint32_t v = raw[w], lo = w ? raw[w - 1] >> 31 : 0u, hi = w + 1 < nwords ? raw[w + 1] << 31 : 0u;
+            flags[g][w] = v | (v << 1) | (v >> 1) | lo | hi;
+        }
+        const uint64_t allowed = 8u + lens[g] * (uint64_t)exc_limit / 1048576u;
+        ok[g] = lens[g] > 0 && (cnt == 0 || (exc_limit > 0 && cnt <= allowed));
+        exc[g] = ok[g] && cnt != 0;
+        if (exc[g]) { any_exc = true; eoff[g] = (uint32_t)ftot; }
+        ftot += nwords;
+        if (ok[g]) { poff[g] = (uint32_t)ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; }
         spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
     }
     ptot += SNK_ARENA_SLACK;
-    std::vector<uint8_t> arena(ptot, 0);
-    for (int g = 0; g < n; ++g) {
-        if (!ok[g]) continue;
-        for (uint64_t i = 0; i < lens[g]; ++i)
-            arena[poff[g] + (i >> 2)] |= (uint8_t)(((seqs[g][i] >> 1) & 3u) << (2u * (i & 3u)));
+    std::vector<uint8_t> arena(ptot, 0), bytes(btot + SNK_PAD, 0), zero(4 * SNK_PAD, 0);
+    std::vector<uint32_t> fl(ftot + 1, 0);
+    {
+        size_t f = 0;
+        for (int g = 0; g < n; ++g) {
+            memcpy(bytes.data() + boff[g], seqs[g], lens[g]);
+            if (exc[g]) memcpy(fl.data() + f, flags[g].data(), flags[g].size() * 4);
+            f += flags[g].size();
+            if (!ok[g]) continue;
+            for (uint64_t i = 0; i < lens[g]; ++i)
+                arena[poff[g] + (i >> 2)] |= (uint8_t)(((seqs[g][i] >> 1) & 3u) << (2u * (i & 3u)));
+        }
     }
-    std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), status(1, 0);
+    std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), snap_gen((size_t)n * 4096, 0), status(1, 0);
+    std::vector<uint32_t> ovf(4096, 0);
 
     SnkTables T;
     memset(&T, 0, sizeof T);
     T.packed_arena = arena.data(); T.packed_off = poff.data(); T.len = len.data();
-    T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data();
-    T.lut_slot = slot.data(); T.header_bytes = header_bytes;
+    T.bytes_arena = bytes.data(); T.bytes_off = boff.data(); T.zero_pad = zero.data();
+    T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data(); T.snap_gen = snap_gen.data();
+    T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.header_bytes = header_bytes;
+    T.exc_flags = fl.data(); T.exc_off = eoff.data(); T.ovf = ovf.data();
 
     blockDim.x = 64; threadIdx.x = 0; blockIdx.x = 0;
     for (int g = 0; g < n; ++g) {
@@ -68,7 +100,8 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
         SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
         SnkFastGrid G; G.jobs = &jb; G.n_jobs = 1u; G.r0 = 0u; G.rows = 1u; G.n = 1u; G.batch = 1u; G.queue = nullptr; G.yorder = nullptr;
-        snk_fast_kernel_body<false>(T, G, 1u, singles, status.data());
+        if (any_exc) snk_fast_kernel_body<false, true>(T, G, 1u, singles, status.data());
+        else         snk_fast_kernel_body<false, false>(T, G, 1u, singles, status.data());
     }
     // all eligible pairs as ONE launch of one lane: the lane walks the job list through the kernel's own
     // hand-out loop (a finished lane takes the next job), alternately as an explicit list and, when every
@@ -90,7 +123,8 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         G.queue = (n & 1) ? &counter : nullptr;          // both schedules get exercised
         if (list.size() == (size_t)n * n) { G.jobs = nullptr; G.n_jobs = (uint32_t)(n * n); }
         else                              { G.jobs = list.data(); G.n_jobs = (uint32_t)list.size(); }
-        snk_fast_kernel_body<false>(T, G, 1u, pairs, status.data());
+        if (any_exc) snk_fast_kernel_body<false, true>(T, G, 1u, pairs, status.data());
+        else         snk_fast_kernel_body<false, false>(T, G, 1u, pairs, status.data());
     }
     return (int)status[0];
 }

@@ -225,6 +225,51 @@ def test_hand_scheduled_steady_loop_equals_its_cxx_statement(hip, oracle_mod):
         assert np.array_equal(p, exp_p), (asm, np.argwhere(p != exp_p)[:8].tolist())
 
 
+def _with_exceptions(rng, a, runs, singles):
+    a = np.array(a, dtype=np.uint8, copy=True)
+    n = len(a)
+    for _ in range(runs):
+        s0 = int(rng.integers(0, n))
+        a[s0:s0 + int(rng.integers(1, 700))] = ord("N")
+    for _ in range(singles):
+        a[int(rng.integers(0, n))] = rng.choice(np.frombuffer(b"NRYKMSWacgtn", dtype=np.uint8))
+    return a
+
+
+def test_sequences_with_a_few_exceptions_stay_on_the_2bit_kernel(hip, oracle_mod):
+    """N runs and scattered IUPAC codes (ref:snacc/pairwise_ncd.py:31-36: every residue is compressed as it is) no
+    longer demote a genome to the byte kernel: the few places go through the 2-bit kernel's byte-accurate
+    general path (sentinel entries + overflow table).  Hand-scheduled and C++ steady loop, prefix snapshots,
+    exceptions at the stream start, at a seam, across a block edge; and next to a sequence that does go to
+    the byte kernel (snapshots in liblz4's layout both ways)."""
+    o = oracle_mod
+    rng = np.random.default_rng(17)
+    g = [o.lcg_genome(200 + k, n) for k, n in enumerate([150000, 131072, 90001, 70000, 200003])]
+    seqs = [_with_exceptions(rng, g[0], 2, 3), g[1], _with_exceptions(rng, g[2], 1, 0), _with_exceptions(rng, g[3], 0, 5),
+            _with_exceptions(rng, g[4], 3, 6), _with_exceptions(rng, o.lcg_mutant(g[0], 9), 1, 2),
+            _tandem(rng, 140000, 300, 0.01)]
+    seqs[2][:40] = ord("N")
+    seqs[3][-30:] = ord("N")
+    seqs[4][65530:65545] = ord("N")
+    seqs[6][70000:70300] = ord("N")
+    heavy = _with_exceptions(rng, o.lcg_genome(210, 120000), 0, 3000)          # too many places: byte kernel
+    for extra, packed in (([], 7), ([heavy], 7)):
+        ss = seqs + extra
+        exp_s = np.array([o.lz4f_size(x) for x in ss], dtype=np.uint32)
+        exp_p = np.array([[o.lz4f_size_pair(a, b) for b in ss] for a in ss], dtype=np.uint32)
+        for asm in (1, 0):
+            with hip.HipContext(0, fast_asm=asm, exc_limit=8192, fast_lanes=5, fast_waves=2) as ctx:
+                ctx.upload(ss)
+                assert ctx.num_packed == packed
+                s, p = ctx.singles(), ctx.pairs()
+            assert np.array_equal(s, exp_s), (asm, np.flatnonzero(s != exp_s))
+            assert np.array_equal(p, exp_p), (asm, np.argwhere(p != exp_p)[:8].tolist())
+    with hip.HipContext(0, exc_limit=0) as ctx:          # the option off: such sequences take the byte kernel, same sizes
+        ctx.upload(seqs)
+        assert ctx.num_packed == 1
+        assert np.array_equal(ctx.pairs(), exp_p[:7, :7])
+
+
 def test_related_genomes_same_ancestor(hip, oracle_mod):
     o = oracle_mod
     anc = o.lcg_genome(40, 180000)
@@ -520,18 +565,22 @@ def test_edge_cases_single_sequence_and_duplicates(hip, oracle_mod):
 
 def test_long_genomes_large_offsets(hip, oracle_mod):
     """12.5 Mbp genomes: stream positions beyond 2^24, 380 blocks per pair, arena offsets in the
-    MB range -- on the 2-bit kernel, and with one N on the (compact) byte kernel."""
+    MB range -- on the 2-bit kernel (one genome with an N: an exception), and with that genome on the (compact) byte kernel."""
     o = oracle_mod
     a, b = o.lcg_genome(301, 12_500_000), o.lcg_genome(302, 12_345_678)
     c = b.copy()
     c[7_000_000] = ord("N")
     seqs = [a, b, c]
-    with hip.HipContext(0) as ctx:
-        ctx.upload(seqs)
-        assert ctx.num_packed == 2
-        s, p = ctx.singles(), ctx.pairs()
-    assert s.tolist() == [o.lz4f_size(x) for x in seqs]
-    assert p.tolist() == [[o.lz4f_size_pair(x, y) for y in seqs] for x in seqs]
+    exp_s = [o.lz4f_size(x) for x in seqs]
+    exp_p = [[o.lz4f_size_pair(x, y) for y in seqs] for x in seqs]
+    # default: the one N is an exception on the 2-bit kernel; exc_limit=0: that genome takes the (compact) byte kernel
+    for opts, packed in (({}, 3), ({"exc_limit": 0}, 2)):
+        with hip.HipContext(0, **opts) as ctx:
+            ctx.upload(seqs)
+            assert ctx.num_packed == packed
+            s, p = ctx.singles(), ctx.pairs()
+        assert s.tolist() == exp_s
+        assert p.tolist() == exp_p
 
 
 def test_emitted_frames_bytes_and_roundtrip(hip, golden, oracle_mod, tmp_path):

@@ -8,11 +8,22 @@ import oracle
 from emu import fast_sizes
 
 
-def expect(seqs):
+def _packable(x, exc_limit):
+    """The kernel's admission rule (snk_upload): pure ACGT, or at most 8 + len * exc_limit / 2^20 flagged granules."""
+    a = np.frombuffer(bytes(x), dtype=np.uint8)
+    if a.size == 0:
+        return False
+    bad = ~np.isin(a, np.frombuffer(b"ACGT", dtype=np.uint8))
+    gran = np.add.reduceat(bad, np.arange(0, a.size, 16)) > 0
+    cnt = int(gran.sum())
+    return cnt == 0 or (exc_limit > 0 and cnt <= 8 + a.size * exc_limit // 1048576)
+
+
+def expect(seqs, exc_limit=128):
     n = len(seqs)
     s = np.zeros(n, np.uint32)
     p = np.zeros((n, n), np.uint32)
-    pure = [len(x) > 0 and set(bytes(x)) <= set(b"ACGT") for x in seqs]
+    pure = [_packable(x, exc_limit) for x in seqs]
     for i in range(n):
         if pure[i] and len(seqs[i]) > 65536:
             s[i] = oracle.lz4f_size(seqs[i])
@@ -22,9 +33,9 @@ def expect(seqs):
     return s, p
 
 
-def check(seqs):
-    s, p = fast_sizes(seqs)
-    es, ep = expect(seqs)
+def check(seqs, exc_limit=128):
+    s, p = fast_sizes(seqs, exc_limit=exc_limit)
+    es, ep = expect(seqs, exc_limit)
     assert np.array_equal(s, es), (s, es)
     assert np.array_equal(p, ep), np.argwhere(p != ep)[:8].tolist()
 
@@ -82,3 +93,52 @@ def test_emu_fuzz(seed):
     if len(seqs[0]) > 200:
         seqs.append(oracle.lcg_mutant(seqs[0], 7)[len(seqs[0]) // 3:])
     check(seqs)
+
+
+def _with_exceptions(rng, a, runs, singles):
+    """N runs and scattered IUPAC codes in an ACGT sequence."""
+    a = a.copy()
+    n = len(a)
+    for _ in range(runs):
+        s0 = int(rng.integers(0, n))
+        a[s0:s0 + int(rng.integers(1, 700))] = ord("N")
+    for _ in range(singles):
+        a[int(rng.integers(0, n))] = rng.choice(np.frombuffer(b"NRYKMSWacgtn", dtype=np.uint8))
+    return a
+
+
+def test_emu_exceptions_n_runs_and_iupac():
+    """Sequences with a few non-ACGT bytes stay on the 2-bit kernel: the places are served by its byte-accurate
+    general path (sentinel entries + overflow table), everything else by the steady loop."""
+    rng = np.random.default_rng(17)
+    o = oracle
+    g = [o.lcg_genome(200 + k, n) for k, n in enumerate([150000, 131072, 90001, 70000, 200003])]
+    seqs = [_with_exceptions(rng, g[0], 2, 3), g[1], _with_exceptions(rng, g[2], 1, 0), _with_exceptions(rng, g[3], 0, 5),
+            _with_exceptions(rng, g[4], 3, 6), _with_exceptions(rng, o.lcg_mutant(g[0], 9), 1, 2)]
+    seqs[2][:40] = ord("N")                          # exceptions at the stream start
+    seqs[3][-30:] = ord("N")                         # ... at the very end (seam of every pair with it in front)
+    seqs[4][65530:65545] = ord("N")                  # ... across a block edge
+    check(seqs, exc_limit=4096)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_emu_exceptions_fuzz(seed):
+    rng = np.random.default_rng(5000 + seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for _ in range(int(rng.integers(3, 6))):
+        n = int(rng.choice([int(rng.integers(66000, 200000)), int(65536 * rng.integers(1, 3) + rng.integers(-20, 21)),
+                            int(rng.integers(20000, 66000))]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            a = rng.choice(acgt, n)
+        elif kind == 1:
+            unit = rng.choice(acgt, int(rng.integers(1, 2000)))
+            a = np.tile(unit, n // len(unit) + 1)[:n].copy()
+            m = rng.random(n) < 0.01
+            a[m] = rng.choice(acgt, int(m.sum()))
+        else:
+            a = np.repeat(rng.choice(acgt, n // 20 + 1), rng.integers(1, 300, n // 20 + 1))[:n].copy()
+        seqs.append(_with_exceptions(rng, a, int(rng.integers(0, 4)), int(rng.integers(0, 8))))
+    seqs.append(_with_exceptions(rng, oracle.lcg_mutant(seqs[0], 7) if set(bytes(seqs[0])) <= set(b"ACGT") else seqs[0].copy(), 1, 1))
+    check(seqs, exc_limit=8192)

@@ -1,0 +1,40 @@
+"""Dev aid: rate of the pair kernel on 1 Mbp genomes with non-ACGT places against pure ACGT ones.
+Usage: gpu_exc.py N L ROWS"""
+import sys
+import numpy as np
+sys.path.insert(0, '.')
+import oracle
+from snacc_amd.hip_backend import HipContext
+N, L, R = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(11)
+base = [oracle.lcg_genome(1 + i, L) for i in range(N)]
+def variant(kind):
+    out = []
+    for a in base:
+        a = a.copy()
+        if kind in ("n10x100", "n10x100+iupac20"):
+            for s0 in rng.integers(0, L - 200, 10):
+                a[s0:s0 + 100] = ord("N")
+        if kind == "n1x1000":
+            s0 = int(rng.integers(0, L - 2000)); a[s0:s0 + 1000] = ord("N")
+        if kind in ("iupac20", "n10x100+iupac20"):
+            a[rng.integers(0, L, 20)] = rng.choice(np.frombuffer(b"RYKMSWN", dtype=np.uint8), 20)
+        if kind == "iupac100":
+            a[rng.integers(0, L, 100)] = rng.choice(np.frombuffer(b"RYKMSWN", dtype=np.uint8), 100)
+        out.append(a)
+    return out
+ref = None
+for kind in ("pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac100"):
+    seqs = variant(kind)
+    ctx = HipContext(0)
+    ctx.upload(seqs)
+    ctx.pairs(0, 2)
+    best = 1e9
+    for _ in range(2):
+        p = ctx.pairs(0, R)
+        best = min(best, ctx.last_pairs_ms())
+    ok = int(p[R - 1, N // 2]) == oracle.lz4f_size_pair(seqs[R - 1], seqs[N // 2])
+    rate = R * N / best * 1e3
+    ref = ref or rate
+    print(f"{kind:18s} packed={ctx.num_packed}/{N} ms={best:.1f} pairs/s={rate:.0f} ({rate / ref * 100:.0f}% of pure) parity={ok}", flush=True)
+    ctx.close()
