@@ -62,6 +62,7 @@ struct snk_ctx_impl {
     bool any_exc = false;
     long exc_limit = 128;            // flagged 16-base granules per 2^20 bases up to which a sequence stays on the 2-bit kernel
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
+    uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr;
     // deflate add-on (snk_deflate.hip): opaque state + its destructor
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
@@ -107,6 +108,7 @@ void free_sequences(snk_ctx_impl *c)
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
     dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0;
+    dfree(c->d_exc_runs); dfree(c->d_exc_roff);
     c->has_exc.clear(); c->any_exc = false;
     c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
     if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
@@ -145,6 +147,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
+    T.exc_runs = c->d_exc_runs; T.exc_roff = c->d_exc_roff;
     T.exc_flags = c->d_exc_flags; T.exc_off = c->d_exc_off; T.lut_h2s = c->d_lut_h2s; T.lut_s2h = c->d_lut_s2h; T.ovf = c->d_ovf;
     T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
@@ -652,6 +655,34 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
                                    d_raw + foff[g], fwords[g], c->d_exc_flags + foff[g]);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        // exact runs of exception bytes, from the caller's (host) bytes of the flagged granules
+        std::vector<uint32_t> runs, roff(n, 0);
+        std::vector<uint32_t> raw;
+        for (size_t g = 0; g < n; ++g) {
+            if (!c->has_exc[g]) continue;
+            raw.resize(fwords[g]);
+            HIPCHK(c, hipMemcpy(raw.data(), d_raw + foff[g], (size_t)fwords[g] * 4, hipMemcpyDeviceToHost));
+            roff[g] = (uint32_t)(runs.size() / 2);
+            bool open = false;
+            for (size_t w = 0; w < fwords[g]; ++w) {
+                uint32_t bits = raw[w];
+                while (bits) {
+                    const size_t gr = w * 32 + (size_t)__builtin_ctz(bits);
+                    bits &= bits - 1;
+                    for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
+                        const uint8_t ch = seqs[g][i];
+                        const bool bad = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+                        if (bad && open && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;       // extends the open run
+                        else if (bad) { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); open = true; }
+                    }
+                }
+            }
+            runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
+        }
+        HIPCHK(c, hipMalloc((void **)&c->d_exc_runs, runs.size() * 4));
+        HIPCHK(c, hipMemcpy(c->d_exc_runs, runs.data(), runs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void **)&c->d_exc_roff, n * 4));
+        HIPCHK(c, hipMemcpy(c->d_exc_roff, roff.data(), n * 4, hipMemcpyHostToDevice));
     }
     dfree(d_raw);
     ptot += SNK_ARENA_SLACK;

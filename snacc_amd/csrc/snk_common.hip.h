@@ -76,6 +76,9 @@ struct SnkTables {
     // 2-bit kernel on sequences with a few non-ACGT bytes ("exceptions": N runs, IUPAC codes; snk_fast.hip.h)
     const uint32_t *exc_flags;        // 1 bit per 16 bases: an exception lies within bases [16g - 16, 16g + 32)
     const uint32_t *exc_off;          // per sequence: its first word in exc_flags, 0xFFFFFFFF = the sequence has none
+    const uint32_t *exc_runs;         // exact runs of non-ACGT bytes, {start, end} pairs sorted by position, each sequence's
+                                      // list ends with {0xFFFFFFFF, 0xFFFFFFFF}
+    const uint32_t *exc_roff;         // per sequence: index of its first pair in exc_runs (only read when exc_off says it has some)
     const uint16_t *lut_h2s;          // [4096] liblz4 hash of 5 bytes -> slot of the 2-bit table, 0xFFFF = no ACGT 5-mer has it
     const uint16_t *lut_s2h;          // [896]  slot -> hash
     uint32_t       *ovf;              // [resident chains][4096] overflow tables (absolute positions, liblz4's own layout)

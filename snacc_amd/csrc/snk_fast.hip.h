@@ -96,7 +96,10 @@ struct SnkFastLane {
     SnkWin w;
     // ---- only used by the instantiations for sequences with exceptions (EXC) ----
     SnkGenSrc g;                           // the ASCII bytes of x and y
-    const uint32_t *fx, *fy;               // dilated exception flags of x / y (NULL: none)
+    const uint32_t *fx, *fy;               // dilated exception flags of x / y (NULL: none): any position, one load, conservative
+    const uint32_t *rx, *ry;               // exact exception runs of x / y ({start, end} pairs, NULL: none): around the cursor
+    uint32_t ri;                           // first run of the cursor's sequence that does not end before the cursor window
+    bool ron_y;                            // ... which sequence that is
     uint32_t *ovf;                         // this chain's overflow table
     uint32_t xlim;                         // first position >= the last scan whose window is not clean
 };
@@ -130,45 +133,58 @@ __device__ __forceinline__ bool snk_exc_clean(const SnkFastLane &L, uint32_t p)
     return false;                                               // the window straddles the seam
 }
 
-// first flagged granule in [g, gend], or 0xFFFFFFFF
-__device__ __forceinline__ uint32_t snk_exc_scan(const uint32_t *f, uint32_t g, uint32_t gend)
+// Exact versions for positions around the cursor, from the sorted run list of the cursor's sequence: the
+// window [q-4, q+12) of sequence position q touches the run [a, b) iff a < q + 12 and b > q - 4.  L.ri only
+// moves forward (the cursor does), so both are O(1) amortised -- no scan of the flag words.
+__device__ __forceinline__ void snk_exc_seek(SnkFastLane &L, uint32_t p)
 {
-    while (g <= gend) {
-        const uint32_t w = f[g >> 5] >> (g & 31u);
-        if (w) {
-            const uint32_t gf = g + (uint32_t)__builtin_ctz(w);
-            return gf <= gend ? gf : 0xFFFFFFFFu;
-        }
-        g = (g | 31u) + 1u;
-    }
-    return 0xFFFFFFFFu;
+    const bool ony = p >= L.s.lx;
+    if (ony != L.ron_y) { L.ron_y = ony; L.ri = 0u; }
+    const uint32_t *r = ony ? L.ry : L.rx;
+    if (!r) return;
+    const uint32_t q = p - (ony ? L.s.lx : 0u);
+    while (r[2u * L.ri + 1u] != 0xFFFFFFFFu && r[2u * L.ri + 1u] + 4u <= q) L.ri++;          // runs that end before [q-4, ...)
 }
 
-// first position p' >= p that is not clean (0xFFFFFFFF: none)
-__device__ __forceinline__ uint32_t snk_exc_next(const SnkFastLane &L, uint32_t p)
+// is the window of position `pos` (the cursor, or a few bases behind it) clean?  Call snk_exc_seek(L, cursor) first.
+__device__ __forceinline__ bool snk_exc_clean_near(const SnkFastLane &L, uint32_t pos)
 {
     const uint32_t lx = L.s.lx;
+    const bool inx = pos + 12u <= lx, iny = pos >= lx + 4u;
+    if (!(inx | iny)) return false;                              // the window straddles the seam
+    const uint32_t *r = iny ? L.ry : L.rx;
+    if (!r || iny != L.ron_y) return r == nullptr;               // (a position in the other sequence than the cursor's: say no)
+    const uint32_t q = pos - (iny ? lx : 0u);
+    for (uint32_t k = L.ri > 0u ? L.ri - 1u : 0u; r[2u * k] != 0xFFFFFFFFu && r[2u * k] < q + 12u; ++k)
+        if (r[2u * k + 1u] + 4u > q) return false;
+    return true;
+}
+
+// first position p' >= p whose window is not clean (0xFFFFFFFF: none); p is the cursor
+__device__ __forceinline__ uint32_t snk_exc_next(SnkFastLane &L, uint32_t p)
+{
+    const uint32_t lx = L.s.lx;
+    snk_exc_seek(L, p);
     if (p + 12u <= lx) {
         const uint32_t stop = lx - 11u;                         // the seam gap at the latest
-        if (!L.fx) return stop;
-        const uint32_t gf = snk_exc_scan(L.fx, p < 4u ? 0u : (p - 4u) >> 4, stop < 5u ? 0u : (stop - 5u) >> 4);
-        if (gf == 0xFFFFFFFFu) return stop;
-        const uint32_t q = 16u * gf + 4u;
-        return q > p ? q : p;
+        if (!L.rx) return stop;
+        const uint32_t a = L.rx[2u * L.ri];                      // first run that does not end before the window
+        if (a == 0xFFFFFFFFu) return stop;
+        const uint32_t q = a < p + 12u ? p : a - 11u;            // touching now, or from a - 11 on
+        return q < stop ? q : stop;
     }
     if (p < lx + 4u) return p;
-    if (!L.fy) return 0xFFFFFFFFu;
-    const uint32_t gf = snk_exc_scan(L.fy, (p - 4u - lx) >> 4, (L.n - lx) >> 4);
-    if (gf == 0xFFFFFFFFu) return 0xFFFFFFFFu;
-    const uint32_t q = lx + 16u * gf + 4u;
-    return q > p ? q : p;
+    if (!L.ry) return 0xFFFFFFFFu;
+    const uint32_t a = L.ry[2u * L.ri];
+    if (a == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+    return a < (p - lx) + 12u ? p : lx + a - 11u;
 }
 
 __device__ __forceinline__ void snk_exc_put(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm, uint32_t h, uint32_t pos)
 {
     const uint32_t s = T.lut_h2s[h];
     if (s != 0xFFFFu) {
-        const bool cl = snk_exc_clean(L, pos);
+        const bool cl = snk_exc_clean_near(L, pos);                 // (every put is at or just behind the cursor)
         tbl[s] = cl ? (uint16_t)(pos - L.base) : (uint16_t)0xFFFFu;
         atomicOr(&bm[s >> 5], 1u << (s & 31u));
         if (!cl) L.ovf[h] = pos;
@@ -298,6 +314,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
         L.base = L.pos - L.k3;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         if (EXC) {
+            snk_exc_seek(L, L.pos);
             snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, L.pos)), L.pos);
         } else {
             const uint32_t w0 = snk_fetch32(L.s, L.pos);
@@ -375,6 +392,7 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
         return snk_fast_block_step<EXC>(L, T, tbl, bm, slot, out, status);
     if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
+        snk_exc_seek(L, cur);
         if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
         const uint32_t h = snk_hash5(snk_ld8(L.g, cur));
         bool valid;
@@ -904,6 +922,9 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                     L.fx = T.exc_off[job.xi] != 0xFFFFFFFFu ? T.exc_flags + T.exc_off[job.xi] : nullptr;
                     L.fy = (job.yi >= 0 && T.exc_off[job.yi] != 0xFFFFFFFFu) ? T.exc_flags + T.exc_off[job.yi] : nullptr;
                     L.ovf = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + lane) * 4096u;
+                    L.rx = L.fx ? T.exc_runs + 2u * T.exc_roff[job.xi] : nullptr;
+                    L.ry = L.fy ? T.exc_runs + 2u * T.exc_roff[job.yi] : nullptr;
+                    L.ri = 0u; L.ron_y = false;
                     L.xlim = 0u;
                 }
             }

@@ -85,6 +85,19 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     }
     std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), snap_gen((size_t)n * 4096, 0), status(1, 0);
     std::vector<uint32_t> ovf(4096, 0);
+    // exact runs of non-ACGT bytes of the sequences with exceptions (as snk_upload builds them)
+    std::vector<uint32_t> runs, roff((size_t)n, 0);
+    for (int g = 0; g < n; ++g) {
+        if (!exc[g]) continue;
+        roff[g] = (uint32_t)(runs.size() / 2);
+        for (uint64_t i = 0; i < lens[g]; ++i) {
+            if (acgt(seqs[g][i])) continue;
+            if (!runs.empty() && runs.size() / 2 > roff[g] && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;
+            else { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); }
+        }
+        runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
+    }
+    runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
 
     SnkTables T;
     memset(&T, 0, sizeof T);
@@ -92,7 +105,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     T.bytes_arena = bytes.data(); T.bytes_off = boff.data(); T.zero_pad = zero.data();
     T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data(); T.snap_gen = snap_gen.data();
     T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.header_bytes = header_bytes;
-    T.exc_flags = fl.data(); T.exc_off = eoff.data(); T.ovf = ovf.data();
+    T.exc_flags = fl.data(); T.exc_off = eoff.data(); T.ovf = ovf.data(); T.exc_runs = runs.data(); T.exc_roff = roff.data();
 
     blockDim.x = 64; threadIdx.x = 0; blockIdx.x = 0;
     for (int g = 0; g < n; ++g) {
