@@ -634,16 +634,49 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dfree(d_cnt);
 
-    // ---- pack ------------------------------------------------------------------------------------
+    // ---- which sequences go to the 2-bit kernel ------------------------------------------------------
+    // Candidates by flagged granules; then the exact runs of exception bytes ("sites") from the caller's bytes of
+    // the flagged granules.  A site costs the wave about 1.5 % of a 1 Mbp pair (byte-accurate probes on cold ASCII
+    // lines + the service exits of the sentinel entries it leaves); the byte kernels run at 29 % (compact table,
+    // e.g. ACGT + N) down to 7 % (full table, e.g. ACGT + several IUPAC codes) of the 2-bit rate: a sequence stays on
+    // the 2-bit kernel up to 4 + 160 sites per 2^20 bases (measured: 100 sites per Mbp 43 %, tools/gpu_exc.py).
     c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false;
-    std::vector<uint32_t> eoff(n, 0xFFFFFFFFu);
-    for (size_t g = 0; g < n; ++g) {
-        const uint64_t allowed = 8u + (uint64_t)lens[g] * (uint64_t)c->exc_limit / 1048576u;
-        c->is_packed[g] = lens[g] > 0 && (ecount[g] == 0 || (c->exc_limit > 0 && ecount[g] <= allowed));
-        c->has_exc[g] = c->is_packed[g] && ecount[g] != 0;
-        if (c->has_exc[g]) { c->any_exc = true; eoff[g] = foff[g]; }
-        if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
+    std::vector<uint32_t> eoff(n, 0xFFFFFFFFu), runs, roff(n, 0);
+    {
+        std::vector<uint32_t> raw;
+        for (size_t g = 0; g < n; ++g) {
+            const uint64_t allowed = 8u + (uint64_t)lens[g] * (uint64_t)c->exc_limit * 8u / 1048576u;     // granules: a first sieve
+            c->is_packed[g] = lens[g] > 0 && (ecount[g] == 0 || (c->exc_limit > 0 && ecount[g] <= allowed));
+            if (!c->is_packed[g] || ecount[g] == 0) continue;
+            raw.resize(fwords[g]);
+            HIPCHK(c, hipMemcpy(raw.data(), d_raw + foff[g], (size_t)fwords[g] * 4, hipMemcpyDeviceToHost));
+            const size_t first = runs.size();
+            for (size_t w = 0; w < fwords[g]; ++w) {
+                uint32_t bits = raw[w];
+                while (bits) {
+                    const size_t gr = w * 32 + (size_t)__builtin_ctz(bits);
+                    bits &= bits - 1;
+                    for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
+                        const uint8_t ch = seqs[g][i];
+                        if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
+                        if (runs.size() > first && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;       // extends the open run
+                        else { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); }
+                    }
+                }
+            }
+            const uint64_t sites = (runs.size() - first) / 2;
+            if (sites > 4u + (uint64_t)lens[g] * 160u / 1048576u * (uint64_t)c->exc_limit / 128u) {
+                runs.resize(first);                                   // too many: the byte kernel serves this one
+                c->is_packed[g] = 0;
+                continue;
+            }
+            roff[g] = (uint32_t)(first / 2);
+            runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
+            c->has_exc[g] = 1; c->any_exc = true; eoff[g] = foff[g];
+        }
     }
+    for (size_t g = 0; g < n; ++g)
+        if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
     HIPCHK(c, hipMalloc((void **)&c->d_exc_off, n * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_exc_off, eoff.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (c->any_exc) {
@@ -655,30 +688,6 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
                                    d_raw + foff[g], fwords[g], c->d_exc_flags + foff[g]);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        // exact runs of exception bytes, from the caller's (host) bytes of the flagged granules
-        std::vector<uint32_t> runs, roff(n, 0);
-        std::vector<uint32_t> raw;
-        for (size_t g = 0; g < n; ++g) {
-            if (!c->has_exc[g]) continue;
-            raw.resize(fwords[g]);
-            HIPCHK(c, hipMemcpy(raw.data(), d_raw + foff[g], (size_t)fwords[g] * 4, hipMemcpyDeviceToHost));
-            roff[g] = (uint32_t)(runs.size() / 2);
-            bool open = false;
-            for (size_t w = 0; w < fwords[g]; ++w) {
-                uint32_t bits = raw[w];
-                while (bits) {
-                    const size_t gr = w * 32 + (size_t)__builtin_ctz(bits);
-                    bits &= bits - 1;
-                    for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
-                        const uint8_t ch = seqs[g][i];
-                        const bool bad = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
-                        if (bad && open && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;       // extends the open run
-                        else if (bad) { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); open = true; }
-                    }
-                }
-            }
-            runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
-        }
         HIPCHK(c, hipMalloc((void **)&c->d_exc_runs, runs.size() * 4));
         HIPCHK(c, hipMemcpy(c->d_exc_runs, runs.data(), runs.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc((void **)&c->d_exc_roff, n * 4));
@@ -956,6 +965,16 @@ int snk_debug_trace(unsigned int from, unsigned int *out /* [1 + 4*4096] */, int
     }
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(snk_trace_n), 4) != hipSuccess) return -1;
     return hipMemcpyFromSymbol(out + 1, HIP_SYMBOL(snk_trace_buf), 4 * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef SNK_STATS
+/* diagnostic build only (not part of the shipped ABI): read and clear the event counters */
+int snk_debug_stats(unsigned int *out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(snk_stats), 16 * sizeof(unsigned int)) != hipSuccess) return -1;
+    unsigned int zero[16] = { 0 };
+    return hipMemcpyToSymbol(HIP_SYMBOL(snk_stats), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif
 

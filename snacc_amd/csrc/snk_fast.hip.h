@@ -104,6 +104,14 @@ struct SnkFastLane {
     uint32_t xlim;                         // first position >= the last scan whose window is not clean
 };
 
+// diagnostic build only (-DSNK_STATS): event counters of the exception machinery (tools/gpu_exc.py prints them)
+#ifdef SNK_STATS
+__device__ unsigned int snk_stats[16];
+#define SNK_COUNT(i) atomicAdd(&snk_stats[i], 1u)
+#else
+#define SNK_COUNT(i) do { } while (0)
+#endif
+
 // =========================================================================
 //  Exceptions: a few non-ACGT bytes in an otherwise 2-bit sequence
 // =========================================================================
@@ -187,8 +195,9 @@ __device__ __forceinline__ void snk_exc_put(SnkFastLane &L, const SnkTables &T, 
         const bool cl = snk_exc_clean_near(L, pos);                 // (every put is at or just behind the cursor)
         tbl[s] = cl ? (uint16_t)(pos - L.base) : (uint16_t)0xFFFFu;
         atomicOr(&bm[s >> 5], 1u << (s & 31u));
-        if (!cl) L.ovf[h] = pos;
+        if (!cl) { L.ovf[h] = pos; SNK_COUNT(6); }
     } else {
+        SNK_COUNT(7);
         L.ovf[h] = pos;
     }
 }
@@ -213,6 +222,7 @@ __device__ __forceinline__ uint32_t snk_exc_get(const SnkFastLane &L, const SnkT
 // liblz4's match accounting on the real bytes (cf. snk_fast_match_slow, which does it on 2-bit windows)
 __device__ __forceinline__ void snk_exc_match(SnkFastLane &L, uint32_t cur, uint32_t cand)
 {
+    SNK_COUNT(4);
     const SnkGenSrc &g = L.g;
     uint32_t ip = cur;
     while (ip > L.anchor && cand > 0u && snk_byte_at(g, ip - 1u) == snk_byte_at(g, cand - 1u)) { ip--; cand--; }
@@ -392,6 +402,7 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
         return snk_fast_block_step<EXC>(L, T, tbl, bm, slot, out, status);
     if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
+        SNK_COUNT(1);
         snk_exc_seek(L, cur);
         if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
         const uint32_t h = snk_hash5(snk_ld8(L.g, cur));
@@ -625,7 +636,8 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 // ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
 template <bool ASM, bool EXC>
-__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off)
+__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off,
+                                                uint32_t round_bases)
 {
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
 #ifdef SNK_HOST_EMU
@@ -643,6 +655,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     const uint32_t limw = w.lim == 0xFFFFFFFFu ? w.lim : w.lim + 1u;
     uint32_t lim_abs = L.mfl1 < limw ? L.mfl1 : limw;
     if (EXC) lim_abs = lim_abs < L.xlim ? lim_abs : L.xlim;       // ... the cursor window must stay clean
+    if (EXC && round_bases != 0xFFFFFFFFu && lim_abs - L.cur > round_bases) lim_abs = L.cur + round_bases;   // a short round
     const uint32_t limc = lim_abs - vb;                           // next probe position >= limc: service
     const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
 
@@ -743,17 +756,44 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         r0 = lo; r1 = hi; rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
         c = ncur; wc = nwc; s1 = ns1; s2 = m ? ns2 : (SNK_FSLOTS - 1u);
     }
+    SNK_COUNT(0);
     // hand every lane over in the state "table operations of the probe at c done, match not evaluated"
     L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
     w.rb = 0x80000000u;                                           // reservoir not kept: the head re-seats it
     if (EXC) {
-        // (T is not needed: the hash comes from the bytes, the overflow table is the lane's)
+        const uint32_t cur = vb + c;
         uint32_t cand = (uint32_t)(T0 + (int32_t)t);
         if ((t & 0xFFFFu) == 0xFFFFu) {                           // sentinel read: the candidate is in the overflow table
-            cand = L.ovf[snk_hash5(snk_ld8(L.g, vb + c))];
-            valid = cand + SNK_MAXDIST >= vb + c;
+            SNK_COUNT(2);
+            cand = L.ovf[snk_hash5(snk_ld8(L.g, cur))];
+            valid = cand + SNK_MAXDIST >= cur;
+            snk_exc_finish(L, cur, cand, valid);                  // ... and not clean: the real bytes decide
+        } else {
+            // Cursor and candidate windows are clean (the loop's invariant; only clean positions get an offset in
+            // the table), so the 2-bit windows -- hot in the L1 -- decide the ordinary cases exactly as the loop
+            // would; a match that may run on beyond them (back-extension 4, 12 bases forward, budget, block end)
+            // is counted on the real bytes, which may hold an exception a little further on.
+            const uint32_t wc2 = snk_fetch32(L.s, cur);
+            const uint32_t wd2 = snk_fetch32(L.s, valid ? cand : cur);
+            const uint32_t x2 = wc2 ^ wd2;
+            const uint32_t f = (uint32_t)__builtin_ctz((x2 >> 8) | (1u << 24)) >> 1;
+            if (!(valid & (f >= 4u))) {
+                const uint32_t s3 = L.nb >> 6;
+                L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
+            } else {
+                const uint32_t eq = (uint32_t)__builtin_clz(((x2 & 0xFFu) << 24) | 0x00800000u) >> 1;
+                uint32_t lit = cur - L.anchor;
+                uint32_t b = eq < lit ? eq : lit;
+                b = b < cand ? b : cand;
+                lit -= b;
+                const uint32_t e2 = cur + f, opn = L.op + lit + 3u;
+                if ((f < 12u) & (b < 4u) & (lit < 15u) & (opn + 6u <= L.olimit) & (e2 < L.mfl1)) {
+                    L.op = opn; L.anchor = e2; L.cur = e2; L.step = 1u; L.nb = 63u; L.pending = true;
+                } else {
+                    snk_exc_match(L, cur, cand);
+                }
+            }
         }
-        snk_exc_finish(L, vb + c, cand, valid);
     } else {
         snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     }
@@ -844,6 +884,8 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     bool dry = false;                            // wave-uniform: no batch left
     bool have = false;                           // this lane works on a pair
     bool parked = false;                         // ... has reached its suffix y and waits for the wave's lanes still inside their x
+    uint32_t waiting = 0u;                       // (EXC) ... stands before an exception site: rounds it has waited for company + 1
+    bool flushing = false;                       // (EXC) wave-uniform: the lanes at exception sites are being served
     SnkFastLane L;
     L.s.lx = 0u; L.cur = 0u;
 
@@ -914,7 +956,7 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                 for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;
             }
             if (take) {
-                snk_fast_lane_init(L, T, job); have = true; need = false; parked = false;
+                snk_fast_lane_init(L, T, job); have = true; need = false; parked = false; waiting = 0u;
                 if (EXC) {
                     L.g.xb = T.bytes_arena + T.bytes_off[job.xi];
                     L.g.yb = job.yi >= 0 ? T.bytes_arena + T.bytes_off[job.yi] : T.zero_pad + SNK_PAD;
@@ -933,6 +975,21 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         }
         if (!__any(have)) return;
 
+        // ---- (EXC) exception sites are served in company ----
+        // The byte-accurate probes of a site cost a few thousand cycles each (cold ASCII lines), during which
+        // the other lanes of the wave stand still.  The lanes of a wave walk the same y a few hundred trips
+        // apart, so a lane that reaches a site waits (masked out of the steady loop, which is then cut into
+        // short rounds) until 8 lanes wait, or it has waited 2 rounds, or nothing else can run; they are then
+        // served together, in lockstep.
+        if (EXC) {
+            const unsigned long long wm = __builtin_amdgcn_ballot_w64(waiting != 0u);
+            if (wm && !flushing &&
+                (__builtin_popcountll(wm) >= 8 || __any(waiting > 2u) || !__any(have && !parked && waiting == 0u)))
+                { flushing = true; if (lane == 0u) SNK_COUNT(3); }
+            if (flushing) waiting = 0u;
+            else if (waiting) waiting++;
+        }
+
         // ---- general probes and reservoir re-seats until every working lane is eligible ----
         bool refill = false;                     // wave-uniform: a lane has finished and a job may be left for it
         for (;;) {
@@ -943,7 +1000,9 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
             if (!anyx) parked = false;
             if (EXC && have && L.cur >= L.xlim && L.cur + L.step <= L.mfl1)
                 L.xlim = snk_exc_next(L, L.cur);             // (the cursor itself when its window is not clean)
-            bool ok = !have || parked || snk_fast_eligible<EXC>(L);
+            if (EXC && !flushing && waiting == 0u && have && L.cur + L.step <= L.mfl1 && L.cur >= L.xlim)
+                { waiting = 1u; SNK_COUNT(5); }              // at an exception site: wait for company
+            bool ok = !have || parked || waiting != 0u || snk_fast_eligible<EXC>(L);
             if (!ok && L.cur + L.step <= L.mfl1) {           // inside a block: can the reservoir be re-seated?
                 const uint32_t cur = L.cur, lx = L.s.lx;
                 if (cur >= lx + 4u) {
@@ -952,13 +1011,15 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                 } else if (cur >= 4u && cur + 12u <= lx)   snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
                 ok = parked || snk_fast_eligible<EXC>(L);
             }
-            if (__builtin_expect(!__any(!ok), 1)) break;
+            if (__builtin_expect(!__any(!ok), 1)) { flushing = false; break; }
             if (!ok && snk_fast_iter<EXC>(L, T, tbl, bm, slot, out, status)) have = false;   // frame complete
             if (!dry && __any(lane_on && !have)) { refill = true; break; }
         }
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
-        if (have && !parked) snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off);
+        const bool company = EXC && __any(waiting != 0u);        // wave-uniform: someone waits at a site: a short round
+        if (have && !parked && waiting == 0u)
+            snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off, company ? 1000u : 0xFFFFFFFFu);
     }
 }
 

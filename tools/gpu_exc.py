@@ -36,5 +36,13 @@ for kind in ("pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac1
     ok = int(p[R - 1, N // 2]) == oracle.lz4f_size_pair(seqs[R - 1], seqs[N // 2])
     rate = R * N / best * 1e3
     ref = ref or rate
+    import ctypes
+    from snacc_amd import hip_backend
+    L_ = hip_backend.load()
+    if hasattr(L_, "snk_debug_stats"):
+        st = (ctypes.c_uint * 16)()
+        L_.snk_debug_stats(st)
+        names = ["steady exits", "general probes", "sentinel reads", "flushes", "byte matches", "site arrivals", "sentinel puts", "ovf-only puts"]
+        print("   stats (upload + 4 launches):", {nm: int(st[i]) for i, nm in enumerate(names)})
     print(f"{kind:18s} packed={ctx.num_packed}/{N} ms={best:.1f} pairs/s={rate:.0f} ({rate / ref * 100:.0f}% of pure) parity={ok}", flush=True)
     ctx.close()
