@@ -10,6 +10,8 @@
 
 #define ITERS 4096
 
+__device__ inline bool i_am_checker(uint32_t tid) { return tid == 0 && blockIdx.x == 0; }
+
 __global__ void k_lat(const uint8_t *arena, uint32_t arena_mask, uint64_t *out, int which, int lanes)
 {
     extern __shared__ uint32_t lds[];
@@ -95,6 +97,29 @@ __global__ void k_lat(const uint8_t *arena, uint32_t arena_mask, uint64_t *out, 
         }
         acc += p;
     }
+    else if (which == 14 || which == 15) {   // dependent ds_read_b64 chain, byte-aligned (14) / ds_read2_b32 dword-aligned (15): a y window in LDS
+        uint32_t off = (tid * 37u) & 0xfffu;
+        uint64_t chk = 0;
+        for (int i = 0; i < ITERS; ++i) {
+            uint64_t v;
+            if (which == 14) asm volatile("ds_read_b64 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)\n\t" : "=v"(v) : "v"(off) : "memory");
+            else             asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1\n\ts_waitcnt lgkmcnt(0)\n\t" : "=v"(v) : "v"((off & ~3u) + 2048u) : "memory");
+            chk ^= v;
+            off = ((uint32_t)v + off * 13u + 5u) & 0xfffu;
+        }
+        acc = off + (uint32_t)chk;
+        if (which == 14 && i_am_checker(tid)) {
+            // correctness of the unaligned read: compare with byte loads
+            uint32_t bad = 0;
+            for (uint32_t o = 0; o < 64u; ++o) {
+                uint64_t v, w = 0;
+                asm volatile("ds_read_b64 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)\n\t" : "=v"(v) : "v"(o) : "memory");
+                for (uint32_t b = 0; b < 8u; ++b) w |= (uint64_t)((const uint8_t *)lds)[2048u + o + b] << (8u * b);
+                bad += v != w;
+            }
+            out[2] = bad;
+        }
+    }
     uint64_t t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0 && (tid >> 6) == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = acc; }
@@ -104,7 +129,7 @@ int main()
 {
     uint8_t *arena; uint64_t *out;
     const size_t asz = (size_t)256 * 65536 + 65536;
-    hipMalloc((void **)&arena, asz); hipMalloc((void **)&out, 16);
+    hipMalloc((void **)&arena, asz); hipMalloc((void **)&out, 32); hipMemset(out, 0xff, 32);
     std::vector<uint8_t> h(asz);
     for (size_t i = 0; i < asz; ++i) h[i] = (uint8_t)((i * 2654435761ull) >> 13);
     hipMemcpy(arena, h.data(), asz, hipMemcpyHostToDevice);
@@ -113,16 +138,17 @@ int main()
                            "global_load_dwordx2 8-aligned dependent (L1)", "VALU independent", "VALU dependent",
                            "VALU + satisfied s_waitcnt", "VALU + SALU", "v_cmp, 2 VALU, v_cndmask (4 instr)", "loop's LDS group (5 ops, wait for 2)",
                            "loop's loads: window (byte aligned) + refill", "loop's loads: window only", "loop's loads: window dword aligned + refill",
-                           "loop's loads: window <= 511 B behind + refill" };
+                           "loop's loads: window <= 511 B behind + refill", "ds_read_b64 byte-aligned dependent", "ds_read2_b32 dword-aligned dependent" };
     for (int lanes : { 21 })
-        for (int grid : { 1, 1024 })
-            for (int w = 0; w < 14; ++w) {
-                uint64_t r[2] = { 0, 0 };
+        for (int grid : { 1024 })
+            for (int w = 0; w < 16; ++w) {
+                uint64_t r[3] = { 0, 0, 0 };
                 for (int rep = 0; rep < 2; ++rep) {
                     hipLaunchKernelGGL(k_lat, dim3(grid), dim3(256), 160 * 1024, 0, arena, 0u, out, w, lanes);
                     hipDeviceSynchronize();
                 }
-                hipMemcpy(r, out, 16, hipMemcpyDeviceToHost);
+                hipMemcpy(r, out, 24, hipMemcpyDeviceToHost);
+                if (w == 14) printf("   unaligned ds_read_b64 vs byte loads: %llu mismatches of 64\n", (unsigned long long)r[2]);
                 const double per = (double)r[0] / ITERS;
                 printf("lanes=%2d grid=%4d  %-52s %8.1f ticks/op (x?%s)\n", lanes, grid, name[w], per, "");
             }
