@@ -90,14 +90,16 @@ def init_process_group(backend, device=None):
         _die(f"init_process_group({backend})", e)
 
 
-def gather_tile(tile, world, group=None, out=None, async_op=False):
+def gather_tile(tile, world, group=None, out=None, async_op=False, force_collective=False):
     """All-gather one (rows, n) int32 tile per rank into a (world * rows, n) tensor on the tile's device
-    (backend "nccl" = RCCL for CUDA tensors, gloo for CPU tensors).  Returns (gathered, work-or-None)."""
+    (backend "nccl" = RCCL for CUDA tensors, gloo for CPU tensors).  Returns (gathered, work-or-None).
+    A single rank copies; `force_collective` makes it call the collective all the same (the one-GPU RCCL
+    smoke test)."""
     import torch
     import torch.distributed as dist
     if out is None:
         out = torch.zeros((world * tile.shape[0], tile.shape[1]), dtype=tile.dtype, device=tile.device)
-    if world == 1:
+    if world == 1 and not force_collective:
         out.copy_(tile)
         return out, None
     try:

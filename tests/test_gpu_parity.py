@@ -697,3 +697,40 @@ def test_save_compression_lz4_cli_and_api(hip, oracle_mod, tmp_path, monkeypatch
     blob = (blobs / "s2s0.fa.lz4").read_bytes()
     assert size == len(blob) + 33 == o.lz4f_size_pair(seqs["s2"], seqs["s0"]) + 33
     assert decode_frame(blob) == seqs["s2"] + seqs["s0"]
+
+
+def test_rccl_single_rank_smoke(hip, oracle_mod, tmp_path):
+    """The only RCCL that one GPU allows: a process group of ONE rank on the nccl backend, through the
+    product's own rendezvous, asynchronous all-gather of a device tile the kernel has just written, wait,
+    allgather_check and barrier (snacc_amd/distributed.py).  It proves the library is there and that the
+    calls, dtypes and stream ordering are accepted; it says nothing about scaling."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29731', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')\n"
+        "import torch, torch.distributed as dist\n"
+        "from snacc_amd import distributed as sd\n"
+        "dev = torch.device('cuda', 0)\n"
+        "sd.init_process_group('nccl', dev)\n"
+        "torch.cuda.set_device(0)\n"
+        "import oracle\n"
+        "from snacc_amd.hip_backend import HipContext\n"
+        "seqs = [oracle.lcg_genome(300 + k, 70000 + 9000 * k) for k in range(5)]\n"
+        "ctx = HipContext(0); ctx.upload(seqs)\n"
+        "tile = torch.zeros((5, 5), dtype=torch.int32, device=dev)\n"
+        "torch.cuda.current_stream(dev).synchronize()\n"
+        "ctx.pairs_device(0, 5, tile.data_ptr(), None); ctx.sync(None)\n"
+        "g, work = sd.gather_tile(tile, 1, async_op=True, force_collective=True)\n"
+        "work.wait(); torch.cuda.synchronize()\n"
+        "assert sd.allgather_check(g, tile, 0, 1)\n"
+        "exp = np.array([[oracle.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)\n"
+        "assert np.array_equal(g.cpu().numpy().view(np.uint32), exp)\n"
+        "dist.barrier(); dist.destroy_process_group(); ctx.close(); print('rccl-ok')\n" % str(tmp_path.parent.parent)
+    )
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parents[1])
+    code = code.replace(repr(str(tmp_path.parent.parent)), repr(root))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0 and "rccl-ok" in res.stdout, (res.stdout[-2000:], res.stderr[-3000:])
