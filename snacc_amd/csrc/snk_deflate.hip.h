@@ -655,13 +655,29 @@ struct DflWave {
     uint32_t n;               // stream length
 };
 
+// Everything in DflWave but `lane` is wave-uniform.  What comes back from a call arrives in VGPRs; this tells the
+// compiler again that the values are uniform, so that the parser state returns to SGPRs.
+__device__ __forceinline__ uint32_t dfl_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t dfl_u64(uint64_t v) { return ((uint64_t)dfl_u32((uint32_t)(v >> 32)) << 32) | dfl_u32((uint32_t)v); }
+template <typename P> __device__ __forceinline__ P *dfl_uptr(P *p) { return (P *)(uintptr_t)dfl_u64((uint64_t)(uintptr_t)p); }
+__device__ __forceinline__ void dfl_uniform(DflWave &w, const DflWave &r)
+{
+    // (the constant members keep the values the caller already holds)
+    w.t_flush = dfl_u64(r.t_flush);
+    w.bits = dfl_u64(r.bits);
+    w.bcount = dfl_u32(r.bcount); w.block_start = dfl_u32(r.block_start); w.nblk = dfl_u32(r.nblk); w.unsafe = dfl_u32(r.unsafe);
+    w.nsym = dfl_u32(r.nsym);
+}
+
 __device__ __forceinline__ void dfl_hist_reset(DflWave &w)
 {
     for (uint32_t i = w.lane; i < DFL_HIST; i += 64u) w.L.hist[i] = i == 256u ? 1u : 0u;
 }
 
 // Close the open block: p0 = loop top of the iteration that closes it, end = strstart at that moment.
-__device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
+// (The wave's state goes in and out BY VALUE: a reference would pin the whole struct to scratch memory and
+// every symbol of the hot loop would then load and store its counters there.)
+__device__ __attribute__((noinline)) DflWave dfl_flush(DflWave w, bool last, uint32_t p0, uint32_t end)
 {
     unsigned long long tf0 = 0, tf1 = 0; (void)tf0; (void)tf1;
     DFL_T(tf0);
@@ -707,6 +723,7 @@ __device__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
     w.block_start = end;
     DFL_T(tf1);
     w.t_flush += tf1 - tf0;
+    return w;
 }
 
 // One symbol from the parser (wave-uniform arguments).  is_match: len/dist valid.
@@ -732,7 +749,7 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
     // (the literal zlib tallies after its main loop never closes a block: the final flush does)
     if (w.price && w.bcount == DFL_BLOCK_SYMS && !tail) {
         __builtin_amdgcn_wave_barrier();
-        dfl_flush(w, false, q + 1u, is_match ? q + len : q + 1u);
+        dfl_uniform(w, dfl_flush(w, false, q + 1u, is_match ? q + len : q + 1u));
     }
 }
 
@@ -832,10 +849,9 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
     const uint32_t hs2 = has2 ? dfl_hash3(S, lx - 2u) : 0xFFFFFFFFu;
     // the (up to) five seam positions whose six bytes mix x and y are in neither sequence's six-byte index:
     // a probe whose hash equals one of theirs takes the full chain walk instead
-    uint32_t ks[5];
-#pragma unroll
-    for (uint32_t i = 0; i < 5u; ++i)
-        ks[i] = (pair && lx >= i + 1u && lx - (i + 1u) + 6u <= n) ? dfl_hash6(dfl_load8(S, lx - (i + 1u))) : 0xFFFFFFFFu;
+    // (lane i < 5 holds the hash of seam position lx - 1 - i: one VGPR and one ballot per probe instead of five uniform values)
+    uint32_t ksl = 0xFFFFFFFFu;
+    if (lane < 5u && pair && lx >= lane + 1u && lx - (lane + 1u) + 6u <= n) ksl = dfl_hash6(dfl_load8(S, lx - (lane + 1u)));
 
     w.n = n; w.unsafe = 0; w.nblk = 0; w.t_flush = 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, acc_search = 0, acc_sync = 0, iters = 0;
@@ -926,7 +942,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
             if (USE_K && total != 0u && la >= DFL_MIN_LOOKAHEAD && (p >= lx || p + 6u <= lx)) {
                 const uint32_t h6 = dfl_hash6(s0);
                 const bool kspecial = pair && p + 5u >= lx && p <= lx + DFL_MAX_DIST + 5u &&
-                                      (h6 == ks[0] || h6 == ks[1] || h6 == ks[2] || h6 == ks[3] || h6 == ks[4]);
+                                      __builtin_amdgcn_ballot_w64(ksl == h6) != 0ull;
                 if (!kspecial) {
                     uint32_t kny = 0, kybase = 0, knx = 0, kxtop = 0;
                     if (p >= lx) {
@@ -1122,7 +1138,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                 const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();
-                dfl_flush(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u);
+                dfl_uniform(w, dfl_flush(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1131,7 +1147,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
     }
     __builtin_amdgcn_wave_barrier();
     DFL_T(t2);
-    if (w.price) dfl_flush(w, true, n, n);
+    if (w.price) dfl_uniform(w, dfl_flush(w, true, n, n));
     DFL_T(t3);
 #ifdef DFL_STAMP
     if (lane == 0 && jid < 64u) {
