@@ -660,24 +660,13 @@ struct DflWave {
 __device__ __forceinline__ uint32_t dfl_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t dfl_u64(uint64_t v) { return ((uint64_t)dfl_u32((uint32_t)(v >> 32)) << 32) | dfl_u32((uint32_t)v); }
 template <typename P> __device__ __forceinline__ P *dfl_uptr(P *p) { return (P *)(uintptr_t)dfl_u64((uint64_t)(uintptr_t)p); }
-__device__ __forceinline__ void dfl_uniform(DflWave &w, const DflWave &r)
-{
-    // (the constant members keep the values the caller already holds)
-    w.t_flush = dfl_u64(r.t_flush);
-    w.bits = dfl_u64(r.bits);
-    w.bcount = dfl_u32(r.bcount); w.block_start = dfl_u32(r.block_start); w.nblk = dfl_u32(r.nblk); w.unsafe = dfl_u32(r.unsafe);
-    w.nsym = dfl_u32(r.nsym);
-}
-
 __device__ __forceinline__ void dfl_hist_reset(DflWave &w)
 {
     for (uint32_t i = w.lane; i < DFL_HIST; i += 64u) w.L.hist[i] = i == 256u ? 1u : 0u;
 }
 
 // Close the open block: p0 = loop top of the iteration that closes it, end = strstart at that moment.
-// (The wave's state goes in and out BY VALUE: a reference would pin the whole struct to scratch memory and
-// every symbol of the hot loop would then load and store its counters there.)
-__device__ __attribute__((noinline)) DflWave dfl_flush(DflWave w, bool last, uint32_t p0, uint32_t end)
+__device__ __forceinline__ void dfl_flush_body(DflWave &w, bool last, uint32_t p0, uint32_t end)
 {
     unsigned long long tf0 = 0, tf1 = 0; (void)tf0; (void)tf1;
     DFL_T(tf0);
@@ -723,10 +712,67 @@ __device__ __attribute__((noinline)) DflWave dfl_flush(DflWave w, bool last, uin
     w.block_start = end;
     DFL_T(tf1);
     w.t_flush += tf1 - tf0;
+}
+
+// The flush as a CALL (it is big, and rare: once per 16 383 symbols).  What it reads and changes goes in and out BY
+// VALUE, in registers: a reference to the wave's state would pin that whole struct to scratch memory, and every
+// symbol of the hot loop would then load and store its counters there (round 1's kernel did: 2.2 MB written per pair).
+// The LDS pointers are derived again from the wave number instead of being passed.
+struct DflBlockState {
+    uint64_t bits; unsigned long long t_flush;
+    uint64_t *cumbits;
+    uint32_t bcount, block_start, nblk, unsafe, n, keep;
+};
+__device__ __forceinline__ void dfl_lds_pointers(DflLds &L, uint32_t wave)
+{
+    extern __shared__ __align__(16) uint8_t dfl_lds[];
+    uint8_t *lds = dfl_lds + wave * L_WAVE;
+    L.hist = (uint32_t *)(lds + L_HIST); L.llen = lds + L_LLEN; L.dlen = lds + L_DLEN;
+    L.blf = (uint16_t *)(lds + L_BLF); L.misc = (uint32_t *)(lds + L_MISC);
+    L.heap = (uint16_t *)(dfl_lds + G_HEAP); L.freq = (uint16_t *)(dfl_lds + G_FREQ); L.dad = (uint16_t *)(dfl_lds + G_DAD);
+    L.len = (uint16_t *)(dfl_lds + G_LEN); L.depth = dfl_lds + G_DEPTH; L.lock = (uint32_t *)(dfl_lds + G_LOCK);
+}
+__device__ __attribute__((noinline)) DflBlockState dfl_flush_call(DflBlockState s, bool last, uint32_t p0, uint32_t end)
+{
+    DflWave w;
+    dfl_lds_pointers(w.L, (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+    w.lane = threadIdx.x & 63u;
+    w.bits = dfl_u64(s.bits); w.t_flush = dfl_u64(s.t_flush); w.cumbits = dfl_uptr(s.cumbits);
+    w.bcount = dfl_u32(s.bcount); w.block_start = dfl_u32(s.block_start); w.nblk = dfl_u32(s.nblk); w.unsafe = dfl_u32(s.unsafe);
+    w.n = dfl_u32(s.n); w.keep_blocks = dfl_u32(s.keep) != 0u;
+    dfl_flush_body(w, last, p0, end);
+    s.bits = w.bits; s.t_flush = w.t_flush; s.bcount = w.bcount; s.block_start = w.block_start; s.nblk = w.nblk; s.unsafe = w.unsafe;
+    return s;
+}
+// The same call with the whole struct passed and returned by value.  Either form keeps the hot loop free of the
+// per-symbol scratch traffic; which one the register allocator likes better differs between the two instantiations of
+// the parse body (measured, pair-compressions/s at 1024 x 1 Mbp: gzip kernel 151.6 k wide / 130.1 k slim, zlib
+// kernel 155.0 k wide / 167.2 k slim), so each uses its better one.
+__device__ __attribute__((noinline)) DflWave dfl_flush_call_wide(DflWave w, bool last, uint32_t p0, uint32_t end)
+{
+    dfl_flush_body(w, last, p0, end);
     return w;
+}
+template <bool WIDE>
+__device__ __forceinline__ void dfl_flush(DflWave &w, bool last, uint32_t p0, uint32_t end)
+{
+    if (WIDE) {
+        const DflWave r = dfl_flush_call_wide(w, last, p0, end);
+        w.bits = dfl_u64(r.bits); w.t_flush = dfl_u64(r.t_flush);
+        w.bcount = dfl_u32(r.bcount); w.block_start = dfl_u32(r.block_start); w.nblk = dfl_u32(r.nblk); w.unsafe = dfl_u32(r.unsafe);
+        return;
+    }
+    DflBlockState s;
+    s.bits = w.bits; s.t_flush = w.t_flush; s.cumbits = w.cumbits; s.bcount = w.bcount; s.block_start = w.block_start;
+    s.nblk = w.nblk; s.unsafe = w.unsafe; s.n = w.n; s.keep = w.keep_blocks ? 1u : 0u;
+    const DflBlockState r = dfl_flush_call(s, last, p0, end);
+    // what comes back from a call arrives in VGPRs: tell the compiler again that it is wave-uniform
+    w.bits = dfl_u64(r.bits); w.t_flush = dfl_u64(r.t_flush);
+    w.bcount = dfl_u32(r.bcount); w.block_start = dfl_u32(r.block_start); w.nblk = dfl_u32(r.nblk); w.unsafe = dfl_u32(r.unsafe);
 }
 
 // One symbol from the parser (wave-uniform arguments).  is_match: len/dist valid.
+template <bool WIDE>
 __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, uint32_t lit, uint32_t len, uint32_t dist, bool tail = false)
 {
     if (w.lane == 0) {
@@ -749,7 +795,7 @@ __device__ __forceinline__ void dfl_emit(DflWave &w, bool is_match, uint32_t q, 
     // (the literal zlib tallies after its main loop never closes a block: the final flush does)
     if (w.price && w.bcount == DFL_BLOCK_SYMS && !tail) {
         __builtin_amdgcn_wave_barrier();
-        dfl_uniform(w, dfl_flush(w, false, q + 1u, is_match ? q + len : q + 1u));
+        dfl_flush<WIDE>(w, false, q + 1u, is_match ? q + len : q + 1u);
     }
 }
 
@@ -815,12 +861,8 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
     if (jid >= njobs) return;
     const DflJob job = jobs[jid];
 
-    uint8_t *lds = dfl_lds + wave * L_WAVE;
     DflWave w;
-    w.L.hist = (uint32_t *)(lds + L_HIST); w.L.llen = lds + L_LLEN; w.L.dlen = lds + L_DLEN;
-    w.L.blf = (uint16_t *)(lds + L_BLF); w.L.misc = (uint32_t *)(lds + L_MISC);
-    w.L.heap = (uint16_t *)(dfl_lds + G_HEAP); w.L.freq = (uint16_t *)(dfl_lds + G_FREQ); w.L.dad = (uint16_t *)(dfl_lds + G_DAD);
-    w.L.len = (uint16_t *)(dfl_lds + G_LEN); w.L.depth = dfl_lds + G_DEPTH; w.L.lock = (uint32_t *)(dfl_lds + G_LOCK);
+    dfl_lds_pointers(w.L, wave);
     w.lane = lane;
 
     const DflSeq sx = T.seq[job.xi];
@@ -1096,7 +1138,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
         DFL_T(tb); acc_search += tb - ta;
         if (prev_length >= 3u && match_length <= prev_length) {
             const uint32_t q = p - 1u;
-            dfl_emit(w, true, q, 0u, prev_length, q - prev_match);
+            dfl_emit<USE_K>(w, true, q, 0u, prev_length, q - prev_match);
             p = q + prev_length;
             match_available = false;
             match_length = 2u;
@@ -1111,7 +1153,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                 if (lo < sy.nsym && lo > 0u && posy[lo] == want && (symy[lo - 1u] >> 31)) { sync_k = lo; break; }
             }
         } else if (match_available) {
-            dfl_emit(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u);
+            dfl_emit<USE_K>(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u);
             p++;
         } else {
             match_available = true;
@@ -1138,16 +1180,16 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                 const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();
-                dfl_uniform(w, dfl_flush(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u));
+                dfl_flush<USE_K>(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u);
             }
         }
         __builtin_amdgcn_wave_barrier();
     } else if (match_available && p >= n) {
-        dfl_emit(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
+        dfl_emit<USE_K>(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
     }
     __builtin_amdgcn_wave_barrier();
     DFL_T(t2);
-    if (w.price) dfl_uniform(w, dfl_flush(w, true, n, n));
+    if (w.price) dfl_flush<USE_K>(w, true, n, n);
     DFL_T(t3);
 #ifdef DFL_STAMP
     if (lane == 0 && jid < 64u) {
@@ -1177,14 +1219,20 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
 
 // The two kernels: with the six-byte index (gzip) the body needs a few more registers and runs best at 7 waves per
 // SIMD; without it (zlib) at 8.  (Measured: 6 / 7 / 8 waves -> gzip 126 / 133 / 118 k, zlib 140 / 153 / 158 k pair-compr/s.)
+#ifndef DFL_WPE_K
+#define DFL_WPE_K 7
+#endif
+#ifndef DFL_WPE
+#define DFL_WPE 8
+#endif
 template <bool SEG>
-__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(7)))
+__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(DFL_WPE_K)))
 dfl_parse_kernel_k(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
     dfl_parse_body<true, SEG>(T, jobs, njobs, out);
 }
 template <bool SEG>
-__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(8)))
+__global__ void __launch_bounds__(64 * DFL_WAVES) __attribute__((amdgpu_waves_per_eu(DFL_WPE)))
 dfl_parse_kernel(DflTables T, const DflJob *jobs, uint32_t njobs, uint32_t *out)
 {
     dfl_parse_body<false, SEG>(T, jobs, njobs, out);
