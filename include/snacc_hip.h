@@ -95,6 +95,9 @@ int snk_num_sequences(const snk_ctx *ctx);
  * Host callers shard rows by work with them (snacc_amd/distributed.py).  Returns SNK_OK. */
 int snk_lengths(const snk_ctx *ctx, uint64_t *lens);
 int snk_num_packed(const snk_ctx *ctx);
+/* Chains (ordered pairs in flight) of one workgroup of the 2-bit kernel under the current options and resident set:
+ * a row tile of this many rows is a whole number of rounds on every compute unit (bench.py sizes its step by it). */
+int snk_fast_chains(snk_ctx *ctx);
 int snk_num_compact_hashes(const snk_ctx *ctx);
 
 /* Phase A (ref:snacc/cli.py:108-116): sizes[i] = len(lz4framed.compress(seq_i)). */

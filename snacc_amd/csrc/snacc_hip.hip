@@ -37,7 +37,8 @@ struct snk_ctx_impl {
 
     // options
     bool fast_asm = true;            // 0 = the C++ statement of the 2-bit kernel's steady loop (cross-checks)
-    int fast_lanes = 21, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;
+    int fast_lanes = 0, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;   // fast_lanes 0 = as many as the LDS holds
+    int fast_ring = 0;               // bytes of the per-wave LDS ring of y in the 2-bit kernel (a power of two), 0 = none
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
     int compact_cap = 0;                       // 0 / 1024 / 2048
@@ -168,6 +169,23 @@ int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
     return SNK_OK;
 }
 
+// Geometry of a 2-bit kernel workgroup under the current options and resident set: chains per wave and ring bytes per wave.
+int fast_geometry(snk_ctx_impl *c, uint32_t *lanes_out, uint32_t *ring_out)
+{
+    const uint32_t waves = (uint32_t)c->fast_waves;
+    const uint32_t ring = c->any_exc ? 0u : (uint32_t)c->fast_ring;    // (the instantiations for exceptions have no ring)
+    const size_t rings = ring ? (size_t)waves * (ring + 8u) : 0u;
+    if (SNK_FLUT_B + rings + (size_t)waves * SNK_FCHAIN_B > 160 * 1024)
+        return fail(c, SNK_E_ARG, "fast_waves = %u with rings of %u bytes exceed the 160 KiB LDS", waves, ring);
+    uint32_t lanes = (uint32_t)c->fast_lanes;
+    if (lanes == 0u) {                // as many chains as fit beside the LUT and the rings
+        lanes = (uint32_t)((160 * 1024 - SNK_FLUT_B - rings) / ((size_t)waves * SNK_FCHAIN_B));
+        if (lanes > 64u) lanes = 64u;
+    }
+    *lanes_out = lanes; *ring_out = ring;
+    return SNK_OK;
+}
+
 // Launch the kernels over a job list laid out as [2-bit jobs | linked byte jobs | one-shot jobs].
 // tile: when non-NULL and its rows > 0, the 2-bit jobs are the dense tile (no list on the device).
 struct SnkTileDesc { uint32_t r0 = 0, rows = 0, n = 0; bool ragged = false; };
@@ -177,17 +195,20 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
 {
     SnkTables T = make_tables(c);
     if (n_fast) {
-        const uint32_t lanes = (uint32_t)c->fast_lanes, waves = (uint32_t)c->fast_waves;
+        const uint32_t waves = (uint32_t)c->fast_waves;
+        const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
+        uint32_t lanes = 0, ring = 0;
+        if (fast_geometry(c, &lanes, &ring) != SNK_OK) return SNK_E_ARG;
+        const size_t rings = ring ? (size_t)waves * (ring + 8u) : 0u;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
+        const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B + rings;
         if (lds > 160 * 1024)
-            return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", chains);
+            return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains (+ rings of %u bytes) exceed the 160 KiB LDS", chains, ring);
         SnkFastGrid G;
         const bool dense = tile && tile->rows > 0;
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
-        G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
-        const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
+        G.batch = lanes; G.queue = nullptr; G.yorder = nullptr; G.ring = ring;
         const void *fk = exc ? (singles ? (const void *)snk_fastx_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
                              : (singles ? (const void *)snk_fast_singles_kernel
@@ -504,11 +525,15 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     if (!c || !key) return fail(c, SNK_E_ARG, "NULL argument");
     std::string k(key);
     if (k == "fast_lanes") {
-        if (value < 1 || value > 64) return fail(c, SNK_E_ARG, "fast_lanes must be 1..64");
+        if (value < 0 || value > 64) return fail(c, SNK_E_ARG, "fast_lanes must be 0 (as many as fit) or 1..64");
         c->fast_lanes = (int)value;
     } else if (k == "fast_waves") {
         if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "fast_waves must be 1..16");
         c->fast_waves = (int)value;
+    } else if (k == "fast_ring") {
+        if (value != 0 && (value < 256 || value > 32768 || (value & (value - 1)) != 0))
+            return fail(c, SNK_E_ARG, "fast_ring must be 0 or a power of two in 256..32768");
+        c->fast_ring = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
     } else if (k == "exc_limit") {
@@ -569,6 +594,13 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
 
 int snk_num_sequences(const snk_ctx *c) { return c ? c->n : SNK_E_ARG; }
 int snk_num_packed(const snk_ctx *c) { return c ? c->n_packed : SNK_E_ARG; }
+int snk_fast_chains(snk_ctx *c)
+{
+    if (!c) return SNK_E_ARG;
+    uint32_t lanes = 0, ring = 0;
+    if (fast_geometry(c, &lanes, &ring) != SNK_OK) return SNK_E_ARG;
+    return (int)(lanes * (uint32_t)c->fast_waves);
+}
 int snk_lengths(const snk_ctx *c, uint64_t *lens)
 {
     if (!c || (c->n && !lens)) return SNK_E_ARG;
@@ -970,10 +1002,10 @@ int snk_debug_trace(unsigned int from, unsigned int *out /* [1 + 4*4096] */, int
 
 #ifdef SNK_STATS
 /* diagnostic build only (not part of the shipped ABI): read and clear the event counters */
-int snk_debug_stats(unsigned int *out16)
+int snk_debug_stats(unsigned long long *out16 /* [32] */)
 {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(snk_stats), 16 * sizeof(unsigned int)) != hipSuccess) return -1;
-    unsigned int zero[16] = { 0 };
+    unsigned long long zero[32] = { 0 };
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(snk_stats), sizeof zero) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(snk_stats), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -20,7 +20,7 @@ ABI_VERSION = 1
 #: every symbol ``include/snacc_hip.h`` declares (checked by the CPU test-suite)
 EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
-    "snk_upload", "snk_num_sequences", "snk_lengths", "snk_num_packed", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
+    "snk_upload", "snk_num_sequences", "snk_lengths", "snk_num_packed", "snk_fast_chains", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms", "snk_pairs_ms_log",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
     "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_pairs_device", "snk_deflate_last_ms",
@@ -96,6 +96,8 @@ def load():
     L.snk_lengths.argtypes = [vp, vp]
     L.snk_num_packed.restype = i32
     L.snk_num_packed.argtypes = [vp]
+    L.snk_fast_chains.restype = i32
+    L.snk_fast_chains.argtypes = [vp]
     L.snk_num_compact_hashes.restype = i32
     L.snk_num_compact_hashes.argtypes = [vp]
     L.snk_singles.restype = i32
@@ -264,6 +266,13 @@ class HipContext:
     @property
     def num_packed(self):
         return self._L.snk_num_packed(self._h)
+
+    def fast_chains(self):
+        """Ordered pairs one workgroup of the 2-bit kernel holds in flight (lanes x waves) under the current options."""
+        rc = self._L.snk_fast_chains(self._h)
+        if rc < 0:
+            self._check(rc, "snk_fast_chains")
+        return rc
 
     @property
     def num_compact_hashes(self):

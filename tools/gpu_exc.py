@@ -40,7 +40,7 @@ for kind in ("pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac1
     from snacc_amd import hip_backend
     L_ = hip_backend.load()
     if hasattr(L_, "snk_debug_stats"):
-        st = (ctypes.c_uint * 16)()
+        st = (ctypes.c_ulonglong * 32)()
         L_.snk_debug_stats(st)
         names = ["steady exits", "general probes", "sentinel reads", "flushes", "byte matches", "site arrivals", "sentinel puts", "ovf-only puts"]
         print("   stats (upload + 4 launches):", {nm: int(st[i]) for i, nm in enumerate(names)})
