@@ -38,7 +38,6 @@ struct snk_ctx_impl {
     // options
     bool fast_asm = true;            // 0 = the C++ statement of the 2-bit kernel's steady loop (cross-checks)
     int fast_lanes = 0, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;   // fast_lanes 0 = as many as the LDS holds
-    int fast_ring = 0;               // bytes of the per-wave LDS ring of y in the 2-bit kernel (a power of two), 0 = none
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
     int compact_cap = 0;                       // 0 / 1024 / 2048
@@ -169,20 +168,18 @@ int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
     return SNK_OK;
 }
 
-// Geometry of a 2-bit kernel workgroup under the current options and resident set: chains per wave and ring bytes per wave.
-int fast_geometry(snk_ctx_impl *c, uint32_t *lanes_out, uint32_t *ring_out)
+// Chains per wave of a 2-bit kernel workgroup under the current options (fast_lanes = 0: as many as the LDS holds).
+int fast_geometry(snk_ctx_impl *c, uint32_t *lanes_out)
 {
     const uint32_t waves = (uint32_t)c->fast_waves;
-    const uint32_t ring = c->any_exc ? 0u : (uint32_t)c->fast_ring;    // (the instantiations for exceptions have no ring)
-    const size_t rings = ring ? (size_t)waves * (ring + 8u) : 0u;
-    if (SNK_FLUT_B + rings + (size_t)waves * SNK_FCHAIN_B > 160 * 1024)
-        return fail(c, SNK_E_ARG, "fast_waves = %u with rings of %u bytes exceed the 160 KiB LDS", waves, ring);
     uint32_t lanes = (uint32_t)c->fast_lanes;
-    if (lanes == 0u) {                // as many chains as fit beside the LUT and the rings
-        lanes = (uint32_t)((160 * 1024 - SNK_FLUT_B - rings) / ((size_t)waves * SNK_FCHAIN_B));
+    if (lanes == 0u) {
+        lanes = (uint32_t)((160 * 1024 - SNK_FLUT_B) / ((size_t)waves * SNK_FCHAIN_B));
         if (lanes > 64u) lanes = 64u;
     }
-    *lanes_out = lanes; *ring_out = ring;
+    if (lanes == 0u || SNK_FLUT_B + (size_t)lanes * waves * SNK_FCHAIN_B > 160 * 1024)
+        return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", lanes * waves);
+    *lanes_out = lanes;
     return SNK_OK;
 }
 
@@ -197,18 +194,15 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     if (n_fast) {
         const uint32_t waves = (uint32_t)c->fast_waves;
         const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
-        uint32_t lanes = 0, ring = 0;
-        if (fast_geometry(c, &lanes, &ring) != SNK_OK) return SNK_E_ARG;
-        const size_t rings = ring ? (size_t)waves * (ring + 8u) : 0u;
+        uint32_t lanes = 0;
+        if (fast_geometry(c, &lanes) != SNK_OK) return SNK_E_ARG;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B + rings;
-        if (lds > 160 * 1024)
-            return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains (+ rings of %u bytes) exceed the 160 KiB LDS", chains, ring);
+        const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         SnkFastGrid G;
         const bool dense = tile && tile->rows > 0;
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
-        G.batch = lanes; G.queue = nullptr; G.yorder = nullptr; G.ring = ring;
+        G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
         const void *fk = exc ? (singles ? (const void *)snk_fastx_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
                              : (singles ? (const void *)snk_fast_singles_kernel
@@ -530,10 +524,6 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "fast_waves") {
         if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "fast_waves must be 1..16");
         c->fast_waves = (int)value;
-    } else if (k == "fast_ring") {
-        if (value != 0 && (value < 256 || value > 32768 || (value & (value - 1)) != 0))
-            return fail(c, SNK_E_ARG, "fast_ring must be 0 or a power of two in 256..32768");
-        c->fast_ring = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
     } else if (k == "exc_limit") {
@@ -597,8 +587,8 @@ int snk_num_packed(const snk_ctx *c) { return c ? c->n_packed : SNK_E_ARG; }
 int snk_fast_chains(snk_ctx *c)
 {
     if (!c) return SNK_E_ARG;
-    uint32_t lanes = 0, ring = 0;
-    if (fast_geometry(c, &lanes, &ring) != SNK_OK) return SNK_E_ARG;
+    uint32_t lanes = 0;
+    if (fast_geometry(c, &lanes) != SNK_OK) return SNK_E_ARG;
     return (int)(lanes * (uint32_t)c->fast_waves);
 }
 int snk_lengths(const snk_ctx *c, uint64_t *lens)

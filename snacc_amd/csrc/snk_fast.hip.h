@@ -24,14 +24,6 @@
 #define SNK_FCHAIN_B    (SNK_FSLOTS * 2u + SNK_FBMWORDS * 4u)      // 1904 bytes
 #define SNK_FLUT_B      2048u                   // slot LUT: 1024 x u16
 
-// diagnostic build only (-DSNK_STATS): event counters of the exception machinery and of the ring (tools/gpu_exc.py, tools/gpu_ring.py)
-#ifdef SNK_STATS
-__device__ unsigned long long snk_stats[32];
-#define SNK_COUNT(i) atomicAdd(&snk_stats[i], 1ull)
-#else
-#define SNK_COUNT(i) do { } while (0)
-#endif
-
 struct SnkFastSrc {
     snk_g8 *arena;            // wave-uniform base of the packed arena (SGPR base + 32-bit lane offsets)
     uint32_t xoff, yoff;      // byte offsets of the two packed sequences inside the arena
@@ -85,56 +77,6 @@ __device__ __forceinline__ void snk_win_init(SnkWin &w, snk_g8 *arena, uint32_t 
     w.r0 = snk_ld4g(p); w.r1 = snk_ld4g(p + 4); w.nx = snk_ld4g(p + 8);
 }
 
-// Per-wave ring of packed arena bytes in LDS (option fast_ring): the lanes of a wave share their suffix y and
-// walk it as one band (see the kernel body), and 99.8 % of all candidates lie within 16 Ki bases behind
-// the cursor, so the last few KB of y serve nearly every candidate window from LDS (~110 cycles) instead
-// of the L1 (~260 in the loop, L2 trips included).  The ring is nothing but a cache of arena bytes:
-// it holds the bytes [lo, hi) of the packed arena, byte a at ring offset a & mask, with the first 8
-// bytes mirrored behind the end so that an 8-byte window never wraps.  A probe uses it when
-// lo <= a and a + 8 <= hi for every lane of the wave (one compare per lane, one branch per trip);
-// any other trip loads from global memory as before.  Refilled by the wave itself whenever it is
-// outside the steady loop; all members are wave-uniform.
-// A refill reaches ring/8 bytes (512 of 4096) beyond the furthest cursor and is due when less than ring/32 (128) are left.
-__device__ __forceinline__ uint32_t snk_ring_ahead(uint32_t rb) { return rb >= 512u ? rb >> 3 : 64u; }
-__device__ __forceinline__ uint32_t snk_ring_low(uint32_t rb) { return rb >= 1024u ? rb >> 5 : 32u; }
-struct SnkRing {
-    uint32_t lds;              // LDS byte address of the ring: mask + 1 + 8 bytes
-    uint32_t mask;             // ring bytes - 1 (a power of two minus one); 0 = no ring
-    uint32_t lo, hi;           // arena bytes held (multiples of 8); lo == hi: empty
-};
-
-#ifdef SNK_HOST_EMU
-static unsigned long long snk_emu_trips[2];      // steady-loop trips of launches with a ring, and those whose candidate window came from it
-__device__ __forceinline__ uint64_t snk_lds_ld8(uint32_t a) { uint64_t v; memcpy(&v, snk_lds8 + a, 8); return v; }
-__device__ __forceinline__ void snk_lds_st8(uint32_t a, uint64_t v) { memcpy(snk_lds8 + a, &v, 8); }
-__device__ __forceinline__ uint32_t snk_lane_value(uint32_t v, uint32_t) { return v; }
-#else
-__device__ __forceinline__ uint64_t snk_lds_ld8(uint32_t a) { return ((const SNK_AS3 SnkU64 *)(uintptr_t)a)->v; }      // byte-aligned
-__device__ __forceinline__ void snk_lds_st8(uint32_t a, uint64_t v) { *(SNK_AS3 uint64_t *)(uintptr_t)a = v; }          // 8-byte aligned
-__device__ __forceinline__ uint32_t snk_lane_value(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-#endif
-
-// Bring the ring up to `front` (arena byte of the furthest cursor of the wave's lanes, wave-uniform):
-// nothing while enough bytes lie ahead of it; else append up to front + ring/8,
-// or start again behind that point when the ring holds another stretch of the arena (a new suffix).
-__device__ __forceinline__ void snk_ring_update(SnkRing &R, snk_g8 *arena, uint32_t front, uint32_t lane)
-{
-    const uint32_t rb = R.mask + 1u;
-    if (R.hi != R.lo && front >= R.lo && front + snk_ring_low(rb) <= R.hi) return;
-    const uint32_t want = (front + snk_ring_ahead(rb) + 7u) & ~7u;
-    uint32_t from = R.hi;
-    if (R.hi == R.lo || front < R.lo || want - R.hi > rb) { from = want - rb; R.lo = from; if (lane == 0u) SNK_COUNT(9); }
-    if (lane == 0u) SNK_COUNT(8);
-    for (uint32_t a = from + 8u * lane; a < want; a += 8u * SNK_COOP(64u)) {
-        const uint64_t v = snk_ld8g(arena + (size_t)a);
-        const uint32_t o = a & R.mask;
-        snk_lds_st8(R.lds + o, v);
-        if (o == 0u) snk_lds_st8(R.lds + rb, v);
-    }
-    R.hi = want;
-    if (R.hi - R.lo > rb) R.lo = R.hi - rb;
-}
-
 // Everything one lane (= one chain = one ordered pair) carries through the flat parse loop.
 struct SnkFastLane {
     SnkFastSrc s;
@@ -162,6 +104,16 @@ struct SnkFastLane {
     uint32_t xlim;                         // first position >= the last scan whose window is not clean
 };
 
+// diagnostic build only (-DSNK_STATS, `make stats`): event counters of the exception machinery (tools/gpu_exc.py) and a
+// cycle account of the waves (tools/gpu_account.py): 0..6 events, 7 wave cycles, 13 cycles inside the steady loop, 14 loop
+// entries, 15 trips of the C++ loop (same trips as the asm loop's), 16..22 why lanes asked for service, 24 finish,
+// 25 / 26 general-probe rounds between two loop entries (cycles / rounds), 27 loop prologue.
+#ifdef SNK_STATS
+__device__ unsigned long long snk_stats[32];
+#define SNK_COUNT(i) atomicAdd(&snk_stats[i], 1ull)
+#else
+#define SNK_COUNT(i) do { } while (0)
+#endif
 
 // =========================================================================
 //  Exceptions: a few non-ACGT bytes in an otherwise 2-bit sequence
@@ -534,9 +486,8 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 #else
 #define SNK_PADE
 #endif
-#define SNK_STEADY_TABLE SNK_STEADY_TABLE_AFTER("")
-#define SNK_STEADY_TABLE_AFTER(HEAD) \
-    "1:\n\t" HEAD \
+#define SNK_STEADY_TABLE \
+    "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
     "ds_read_u16 v91, v90\n\t" \
@@ -606,8 +557,6 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 // compare, next cursor, next window + LUT reads, accounting, exit test (LIM = limit register)
 #define SNK_STEADY_REST(LIM) \
     "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
-    SNK_STEADY_REST_BODY(LIM, SNK_STEADY_TAIL_PLAIN)
-#define SNK_STEADY_REST_BODY(LIM, TAIL) \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
     "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
@@ -642,53 +591,6 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_cmp_ge_u32_e64 %[st], %[c], " LIM "\n\t" \
     "s_or_b64 vcc, vcc, %[st]\n\t" \
     "s_cbranch_vccz 1b\n\t" \
-    TAIL
-#define SNK_STEADY_TAIL_PLAIN "s_waitcnt lgkmcnt(0)\n\t"
-// ---- the y-only loop with the wave's LDS ring of y (SnkRing) ----
-// The candidate window is read from the ring speculatively (address = ring base + (arena byte & mask): any address is
-// harmless), the range test (lo <= a, a + 8 <= hi, one unsigned compare) runs beside it, and ONE wave-uniform branch
-// sends the trip to the slow block when some lane's window is not in the ring: that block waits for the LDS read to
-// retire, loads the window from global memory as the plain loop does, and joins again in front of the compare.
-#define SNK_STEADY_RINGADDR \
-    "v_and_b32_e32 v101, %[rmask], v104\n\t" \
-    "v_add_u32_e32 v101, %[rbase], v101\n\t"
-// (the refill of the cursor's reservoir, the loop's one remaining L1 access, is issued at the top of the trip: nothing else is in
-// flight to hide its latency behind, and the slot of cur is being waited for there anyway)
-#define SNK_STEADY_RING_REFILL \
-    "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
-    "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
-    "global_load_dword v108, %[nxoff], %[arena]\n\t"
-#define SNK_STEADY_SHADOW_HEAD_RING \
-    "ds_read_b64 v[106:107], v101\n\t" \
-    "v_subrev_u32_e32 v100, %[rlo], v104\n\t" \
-    "v_cmp_lt_u32_e32 vcc, %[rspan], v100\n\t" \
-    "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t" \
-    "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm]\n\t" \
-    "s_cbranch_vccnz 5f\n\t"
-#define SNK_STEADY_SHADOW_TAIL(PH) \
-    "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t" \
-    "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t" \
-    "v_sub_u32_e32 v124, %[op], %[oz]\n\t" \
-    "v_cmp_gt_u32_e64 %[sv], %[t], %[c]\n\t" \
-    "v_and_b32_e32 v109, 3, " PH "\n\t" \
-    "v_lshlrev_b32_e32 v109, 1, v109\n\t" \
-    "v_add_u32_e32 v111, %[T0], %[t]\n\t" \
-    "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
-#define SNK_STEADY_RING_LOOP(LIM) \
-    SNK_STEADY_TABLE_AFTER(SNK_STEADY_RING_REFILL) SNK_STEADY_ADDR_YONLY SNK_STEADY_RINGADDR SNK_STEADY_SHADOW_HEAD_RING \
-    SNK_STEADY_SHADOW_TAIL("%[t]") SNK_PADC \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    "4:\n\t" \
-    SNK_STEADY_REST_BODY(LIM, SNK_STEADY_TAIL_RING)
-#define SNK_STEADY_TAIL_RING \
-    "s_branch 6f\n\t" \
-    "5:\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
-    SNK_STEADY_SHADOW_TAIL("%[t]") \
-    "s_waitcnt vmcnt(0)\n\t" \
-    "s_branch 4b\n\t" \
-    "6:\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t"
 #define SNK_STEADY_OPERANDS \
     : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
@@ -697,7 +599,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st) \
     : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
       [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
-      [arena] "s"(arena), [rlo] "s"(rlo_s), [rspan] "s"(rspan_s), [rmask] "s"(rmask_s), [rbase] "s"(rbase_s) \
+      [arena] "s"(arena) \
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
@@ -738,9 +640,13 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
 template <bool ASM, bool EXC>
 __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off,
-                                                uint32_t round_bases, const SnkRing &R)
+                                                uint32_t round_bases)
 {
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
+#ifdef SNK_STATS
+    const unsigned long long stat_te = clock64();
+    const bool stat_first = (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+#endif
 #ifdef SNK_HOST_EMU
     const uint16_t *const lut0 = slot;
 #else
@@ -757,23 +663,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     uint32_t lim_abs = L.mfl1 < limw ? L.mfl1 : limw;
     if (EXC) lim_abs = lim_abs < L.xlim ? lim_abs : L.xlim;       // ... the cursor window must stay clean
     if (EXC && round_bases != 0xFFFFFFFFu && lim_abs - L.cur > round_bases) lim_abs = L.cur + round_bases;   // a short round
-    // ring (wave-uniform): candidate windows come from LDS in every trip in which all of them lie inside it.  A lane
-    // whose cursor is inside leaves the loop shortly before it reaches the ring's end, so that the wave refills.
-    const bool ring_on = !EXC && R.mask != 0u && R.hi - R.lo >= 64u;
-    const uint32_t ring_span = R.hi - R.lo - 8u;                  // candidate byte a is served when a - lo <= span
-    if (ring_on && L.cur >= L.s.lx + 4u) {
-        const uint32_t cb = L.s.yoff + ((L.cur - L.s.lx) >> 2);
-        if (cb >= R.lo && cb + 16u <= R.hi) {
-            const uint32_t lr = L.cur + 4u * (R.hi - 16u - cb);
-            lim_abs = lim_abs < lr ? lim_abs : lr;
-        }
-    }
     const uint32_t limc = lim_abs - vb;                           // next probe position >= limc: service
     const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
-#ifdef SNK_STATS
-    const unsigned long long stat_t0 = clock64();
-    const bool stat_first = (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
-#endif
 
     uint32_t c = L.cur - vb, anchor_c = L.anchor - vb, op = L.op;
     uint32_t r0 = w.r0, r1 = w.r1, r2 = w.nx;
@@ -790,6 +681,10 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
     }
     uint32_t t; bool valid;
+#ifdef SNK_STATS
+    const unsigned long long stat_t0 = clock64();
+    if (stat_first) atomicAdd(&snk_stats[27], stat_t0 - stat_te);
+#endif
 #ifndef SNK_HOST_EMU
     if (ASM) {
         uint32_t lit;
@@ -799,14 +694,9 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         uint32_t opn = op;                                            // ... committing it again changes nothing
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
-        // the ring's parameters are wave-uniform by construction: into SGPRs
-        const uint32_t rlo_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.lo), rspan_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_span);
-        const uint32_t rmask_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.mask), rbase_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.lds);
         // every lane's block wholly > 64 KiB past its seam (no t can land in x or on the seam)?
         if (!EXC) {
-            if (__all(sx + 15 <= 0) && ring_on)
-                asm volatile(SNK_STEADY_RING_LOOP("%[limc]") SNK_STEADY_OPERANDS);
-            else if (__all(sx + 15 <= 0))
+            if (__all(sx + 15 <= 0))
                 asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
                              SNK_STEADY_OPERANDS);
             else
@@ -839,16 +729,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         // ---- candidate window (global, L1) and the reservoir refill, in flight together ----
         const bool inx = (int32_t)t < sx;
         const uint32_t tt = t + (inx ? kx : 0u);
-        const uint32_t ca = (inx ? xoffB : yoffB) + (tt >> 2);
-        const bool inr = ring_on && ca - R.lo <= ring_span;           // (one unsigned compare: lo <= ca and ca + 8 <= hi)
-        const uint64_t v = (ring_on && !__any(!inr)) ? snk_lds_ld8(R.lds + (ca & R.mask)) : snk_ld8g(arena + (size_t)ca);
-        SNK_COUNT(10); if (ring_on && !__any(!inr)) SNK_COUNT(11); if (inr) SNK_COUNT(12);
-#ifdef SNK_STATS
-        if (stat_first) SNK_COUNT(15);
-#endif
-#ifdef SNK_HOST_EMU
-        if (R.mask != 0u) { snk_emu_trips[0]++; if (ring_on && inr) snk_emu_trips[1]++; }      // (CPU tests: the ring does serve the windows)
-#endif
+        const uint64_t v = snk_ld8g(arena + (size_t)((inx ? xoffB : yoffB) + (tt >> 2)));
         r2 = snk_ld4g(arena + (size_t)nxoff);
         const bool straddle = valid & ((uint32_t)((int32_t)t - sx) < 15u);
         const uint32_t lit = c - anchor_c;
@@ -880,7 +761,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         const bool svc = (mx >= 15) | (ncur >= limc) | straddle | (EXC && e == 0xFFFFu);       // sentinel: position in the overflow table
         SNK_TRACE_REC(3u, vb + c, (uint32_t)(T0 + (int32_t)t), (r << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), vb + c);
 #ifdef SNK_STATS
-        if (svc) {          // why lanes ask for service (a lane may have several reasons; a wave exit may have several lanes)
+        if (stat_first) SNK_COUNT(15);
+        if (svc) {          // why lanes ask for service (a lane may have several reasons; an exit may serve several lanes)
             if ((int32_t)lit >= 15) SNK_COUNT(16);
             if (b >= 4u) SNK_COUNT(17);
             if ((int32_t)op - olimZ + 14 >= 15) SNK_COUNT(18);
@@ -898,7 +780,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     }
     SNK_COUNT(0);
 #ifdef SNK_STATS
-    if (stat_first) { atomicAdd(&snk_stats[13], clock64() - stat_t0); atomicAdd(&snk_stats[14], 1ull); }
+    const unsigned long long stat_t1 = clock64();
+    if (stat_first) { atomicAdd(&snk_stats[13], stat_t1 - stat_t0); atomicAdd(&snk_stats[14], 1ull); }
 #endif
     // hand every lane over in the state "table operations of the probe at c done, match not evaluated"
     L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
@@ -940,6 +823,9 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     } else {
         snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     }
+#ifdef SNK_STATS
+    if (stat_first) atomicAdd(&snk_stats[24], clock64() - stat_t1);
+#endif
 }
 
 // How job numbers map to ordered pairs, and how the waves of a launch share them.
@@ -959,7 +845,6 @@ struct SnkFastGrid {
     uint32_t *queue;          // starts at (waves of the launch); NULL = static round robin
     const uint32_t *yorder;   // dense tile: column visited k-th (longest suffix first when lengths are ragged: the
                               // big jobs go out first and the launch ends on small ones); NULL = column k
-    uint32_t ring;            // bytes of the per-wave ring of y in LDS (a power of two), 0 = none (see SnkRing)
 };
 
 __device__ __forceinline__ SnkJob snk_fast_job(const SnkFastGrid &G, uint32_t q)
@@ -1022,11 +907,6 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     uint8_t *const mine = snk_lds8 + mine_off;
     uint16_t *const tbl = (uint16_t *)mine;
     uint32_t *const bm = (uint32_t *)(mine + SNK_FSLOTS * 2u);
-
-    SnkRing R;                                   // behind the chains: one ring of G.ring + 8 bytes per wave
-    R.mask = EXC ? 0u : (G.ring ? G.ring - 1u : 0u);
-    R.lds = SNK_FLUT_B + waves * lanes * SNK_FCHAIN_B + wave * (G.ring + 8u);
-    R.lo = R.hi = 0u;
 
     const uint32_t n_batches = (G.n_jobs + G.batch - 1u) / G.batch;
     const uint32_t wid = blockIdx.x * waves + wave, wtotal = gridDim.x * waves;
@@ -1149,7 +1029,13 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 
         // ---- general probes and reservoir re-seats until every working lane is eligible ----
         bool refill = false;                     // wave-uniform: a lane has finished and a job may be left for it
+#ifdef SNK_STATS
+        const unsigned long long stat_i0 = clock64();
+#endif
         for (;;) {
+#ifdef SNK_STATS
+            if (lane == 0u) SNK_COUNT(26);
+#endif
             // Lanes of a wave share their suffix y (jobs are suffix-major) but reach it after x tails of
             // different lengths.  A lane that arrives parks until no lane of the wave is inside its x any
             // more: the wave then walks y as one band of a few KB and the L1 keeps serving the windows.
@@ -1172,22 +1058,14 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
             if (!ok && snk_fast_iter<EXC>(L, T, tbl, bm, slot, out, status)) have = false;   // frame complete
             if (!dry && __any(lane_on && !have)) { refill = true; break; }
         }
+#ifdef SNK_STATS
+        if (lane == 0u) atomicAdd(&snk_stats[25], clock64() - stat_i0);
+#endif
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
         const bool company = EXC && __any(waiting != 0u);        // wave-uniform: someone waits at a site: a short round
-        const bool go = have && !parked && waiting == 0u;
-        if (!EXC && R.mask != 0u) {
-            // the ring follows the furthest cursor among the lanes that are past their seam (they share y, or will soon)
-            uint32_t front = 0u;
-            for (unsigned long long m = __builtin_amdgcn_ballot_w64(go && L.cur >= L.s.lx + 4u); m; m &= m - 1ull) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(m);
-                const uint32_t cb = snk_lane_value(L.s.yoff + ((L.cur - L.s.lx) >> 2), l);
-                front = cb > front ? cb : front;
-            }
-            if (front != 0u) snk_ring_update(R, (snk_g8 *)T.packed_arena, front, lane);
-        }
-        if (go)
-            snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off, company ? 1000u : 0xFFFFFFFFu, R);
+        if (have && !parked && waiting == 0u)
+            snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off, company ? 1000u : 0xFFFFFFFFu);
     }
 }
 

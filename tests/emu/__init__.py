@@ -21,11 +21,10 @@ def build():
     return _SO
 
 
-def fast_sizes(seqs, header_bytes=7, exc_limit=128, ring=0):
+def fast_sizes(seqs, header_bytes=7, exc_limit=128):
     """(singles[n], pairs[n, n]) frame sizes the 2-bit kernel's code computes; 0 where the pair is not
     eligible for that kernel (n <= 64 KiB, or a sequence with more non-ACGT places than `exc_limit`
-    16-base granules per 2^20 bases (+8) allows; exc_limit=0: pure ACGT only).  ring: bytes of the wave's LDS
-    ring of y (a power of two >= 256; 0 = none; ignored when a sequence of the set has exceptions)."""
+    16-base granules per 2^20 bases (+8) allows; exc_limit=0: pure ACGT only)."""
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -38,14 +37,8 @@ def fast_sizes(seqs, header_bytes=7, exc_limit=128, ring=0):
     singles = np.zeros(n, dtype=np.uint32)
     pairs = np.zeros((n, n), dtype=np.uint32)
     rc = _lib.emu_fast_sizes(n, ptrs, lens, singles.ctypes.data_as(ctypes.c_void_p),
-                             pairs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(header_bytes), ctypes.c_uint32(exc_limit), ctypes.c_uint32(ring))
+                             pairs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(header_bytes), ctypes.c_uint32(exc_limit))
     if rc != 0:
         raise RuntimeError(f"emulated kernel reported status {rc}")
     return singles, pairs
 
-
-def fast_trips():
-    """(steady-loop trips, trips served by the ring) of all fast_sizes calls of this process so far."""
-    out = (ctypes.c_ulonglong * 2)()
-    _lib.emu_fast_trips(out)
-    return int(out[0]), int(out[1])

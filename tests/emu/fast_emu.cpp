@@ -22,7 +22,7 @@ bool acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 // exc_limit: flagged 16-base granules per 2^20 bases (+8) up to which a sequence with non-ACGT bytes stays on
 // the 2-bit kernel (0: pure ACGT only).  Entries of `singles` / `pairs` that the kernel does not serve stay 0.
 extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t *lens,
-                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit, uint32_t ring)
+                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit)
 {
     const char code2byte[4] = { 'A', 'C', 'T', 'G' };
     std::vector<uint16_t> slot(1024, 0), h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);
@@ -112,7 +112,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         singles[g] = 0;
         if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
         SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
-        SnkFastGrid G; G.jobs = &jb; G.n_jobs = 1u; G.r0 = 0u; G.rows = 1u; G.n = 1u; G.batch = 1u; G.queue = nullptr; G.yorder = nullptr; G.ring = 0u;
+        SnkFastGrid G; G.jobs = &jb; G.n_jobs = 1u; G.r0 = 0u; G.rows = 1u; G.n = 1u; G.batch = 1u; G.queue = nullptr; G.yorder = nullptr;
         if (any_exc) snk_fast_kernel_body<false, true>(T, G, 1u, singles, status.data());
         else         snk_fast_kernel_body<false, false>(T, G, 1u, singles, status.data());
     }
@@ -128,7 +128,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
             list.push_back(jb);
         }
     if (!list.empty()) {
-        SnkFastGrid G; G.r0 = 0u; G.rows = (uint32_t)n; G.n = (uint32_t)n; G.batch = 3u; G.ring = ring;
+        SnkFastGrid G; G.r0 = 0u; G.rows = (uint32_t)n; G.n = (uint32_t)n; G.batch = 3u;
         std::vector<uint32_t> order((size_t)n);
         for (int k = 0; k < n; ++k) order[(size_t)k] = (uint32_t)(n - 1 - k);
         G.yorder = (n & 2) ? order.data() : nullptr;
@@ -142,5 +142,3 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     return (int)status[0];
 }
 
-// steady-loop trips of the calls so far, and how many of them took their candidate window from the ring
-extern "C" void emu_fast_trips(unsigned long long *out) { out[0] = snk_emu_trips[0]; out[1] = snk_emu_trips[1]; }

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
-from emu import fast_sizes, fast_trips
+from emu import fast_sizes
 
 
 def _packable(x, exc_limit):
@@ -33,27 +33,22 @@ def expect(seqs, exc_limit=128):
     return s, p
 
 
-def check(seqs, exc_limit=128, rings=(0,)):
+def check(seqs, exc_limit=128):
+    s, p = fast_sizes(seqs, exc_limit=exc_limit)
     es, ep = expect(seqs, exc_limit)
-    for ring in rings:
-        s, p = fast_sizes(seqs, exc_limit=exc_limit, ring=ring)
-        assert np.array_equal(s, es), (ring, s, es)
-        assert np.array_equal(p, ep), (ring, np.argwhere(p != ep)[:8].tolist())
-
-
-# ring sizes of the wave's LDS window of y: none, a tiny one (refills, wrap-around and restarts all the time), the shipped one
-RINGS = (0, 256, 4096)
+    assert np.array_equal(s, es), (s, es)
+    assert np.array_equal(p, ep), np.argwhere(p != ep)[:8].tolist()
 
 
 def test_emu_ragged_block_edges():
     lens = [65536, 65537, 131072, 200001, 30000, 35536, 12, 65535 + 65536, 131073, 70000]
-    check([oracle.lcg_genome(11 + k, n) for k, n in enumerate(lens)], rings=RINGS)
+    check([oracle.lcg_genome(11 + k, n) for k, n in enumerate(lens)])
 
 
 def test_emu_lengths_mod_4_and_seams():
     # every residue of len(x) mod 4 (the phase of y inside the packed words) and seams next to block edges
     lens = [100001, 100002, 100003, 100004, 65530, 65533, 131069, 131075, 5, 6, 7]
-    check([oracle.lcg_genome(31 + k, n) for k, n in enumerate(lens)], rings=RINGS)
+    check([oracle.lcg_genome(31 + k, n) for k, n in enumerate(lens)])
 
 
 def test_emu_repeats_long_matches_and_runs():
@@ -61,12 +56,12 @@ def test_emu_repeats_long_matches_and_runs():
            oracle.lcg_mutant(np.tile(oracle.lcg_genome(32, 5000), 40), 5),
            np.frombuffer(b"A" * 150000, dtype=np.uint8), oracle.lcg_genome(33, 160000),
            np.frombuffer(b"AC" * 40000, dtype=np.uint8)]
-    check(rep, rings=RINGS)
+    check(rep)
 
 
 def test_emu_relatives():
     a = oracle.lcg_genome(41, 180000)
-    check([a, oracle.lcg_mutant(a, 3), oracle.lcg_mutant(a, 4)[1000:], oracle.lcg_genome(42, 90000)], rings=RINGS)
+    check([a, oracle.lcg_mutant(a, 3), oracle.lcg_mutant(a, 4)[1000:], oracle.lcg_genome(42, 90000)])
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -97,7 +92,7 @@ def test_emu_fuzz(seed):
         seqs.append(a)
     if len(seqs[0]) > 200:
         seqs.append(oracle.lcg_mutant(seqs[0], 7)[len(seqs[0]) // 3:])
-    check(seqs, rings=RINGS)
+    check(seqs)
 
 
 def _with_exceptions(rng, a, runs, singles):
@@ -147,15 +142,3 @@ def test_emu_exceptions_fuzz(seed):
         seqs.append(_with_exceptions(rng, a, int(rng.integers(0, 4)), int(rng.integers(0, 8))))
     seqs.append(_with_exceptions(rng, oracle.lcg_mutant(seqs[0], 7) if set(bytes(seqs[0])) <= set(b"ACGT") else seqs[0].copy(), 1, 1))
     check(seqs, exc_limit=8192)
-
-
-def test_emu_ring_serves_the_candidate_windows():
-    """With the wave's LDS ring of y switched on, nearly every steady-loop trip on random genomes takes its candidate
-    window from the ring (16 Ki bases of y behind the cursor), and the sizes stay the oracle's."""
-    seqs = [oracle.lcg_genome(71, 300000), oracle.lcg_genome(72, 280000)]
-    fast_sizes(seqs[:1])                                  # (loads the library)
-    t0, r0 = fast_trips()
-    check(seqs, rings=(4096,))
-    t1, r1 = fast_trips()
-    assert t1 - t0 > 100000
-    assert (r1 - r0) / (t1 - t0) > 0.85, ((r1 - r0), (t1 - t0))

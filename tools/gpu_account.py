@@ -1,0 +1,45 @@
+"""Dev aid (GPU box): cycle account of the 2-bit kernel's waves from the stats build (`make -C snacc_amd/csrc stats`).
+Runs a row tile once with the hand-scheduled loop (cycles) and once with its C++ statement (trips and service reasons: the two
+loops make the same trips), and prints cycles per trip, the cost of leaving and re-entering the loop, and why lanes ask for service.
+Usage: SNACC_HIP_LIB=$PWD/snacc_amd/libsnacc_hip_stats.so python tools/gpu_account.py [N L]   (default 256 x 1 Mbp, rows = chains)"""
+import ctypes
+import json
+import sys
+sys.path.insert(0, '.')
+import oracle
+from snacc_amd import hip_backend
+from snacc_amd.hip_backend import HipContext
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+seqs = [oracle.lcg_genome(1 + i, L) for i in range(N)]
+lib = hip_backend.load()
+if not hasattr(lib, "snk_debug_stats"):
+    sys.exit("not the stats build: set SNACC_HIP_LIB to libsnacc_hip_stats.so")
+
+
+def run(asm):
+    st = (ctypes.c_ulonglong * 32)()
+    with HipContext(0, fast_asm=asm) as ctx:
+        ctx.upload(seqs)
+        lib.snk_debug_stats(st)                      # (reads and clears: drop the upload's single-sequence pass)
+        rows = ctx.fast_chains()
+        ctx.pairs(0, rows)
+        ms = ctx.last_pairs_ms()
+        lib.snk_debug_stats(st)
+    return rows, ms, [int(v) for v in st]
+
+
+rows, ms, a = run(1)
+_, _, c = run(0)
+pairs = rows * N
+trips, entries = c[15], a[14]
+out = {"genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
+       "wave_trips": trips, "loop_entries": entries, "trips_per_entry": trips / entries,
+       "cycles_per_trip_in_loop": a[13] / trips,
+       "cycles_per_exit_outside_loop": (a[7] - a[13]) / entries,
+       "share_outside_loop": (a[7] - a[13]) / a[7],
+       "per_exit": {"finish": a[24] / entries, "general_rounds_and_reseat": a[25] / entries, "rounds": a[26] / entries, "prologue": a[27] / entries},
+       "service_requests_per_pair": {k: c[i] / pairs for i, k in [(16, "literal run >= 15"), (17, "back-extension 4"), (18, "output budget"),
+                                                                  (19, "12 equal bases"), (20, "block end"), (21, "other limit"), (22, "seam straddle")]}}
+print(json.dumps(out, indent=1))
