@@ -61,7 +61,7 @@ int snk_ctx_create(int device, snk_ctx **out);
 void snk_ctx_destroy(snk_ctx *ctx);
 
 /* Tunables (all optional).  Keys:
- *   "fast_lanes"    chains (lanes) per wavefront in the 2-bit ACGT kernel
+ *   "fast_lanes"    chains (lanes) per wavefront in the 2-bit ACGT kernel; 0 (default) = as many as the LDS holds
  *   "fast_waves"    wavefronts per workgroup in the 2-bit ACGT kernel
  *   "bytes_lanes", "bytes_waves", "cbytes_*", "c2bytes_*"  the same for the byte kernels
  *                   (full table / compact 1024 slots / compact 2048 slots)

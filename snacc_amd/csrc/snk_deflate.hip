@@ -52,8 +52,9 @@ struct DflState {
     DflSeq *d_seq = nullptr;
     uint32_t *d_occ = nullptr, *d_bstart = nullptr;
     uint64_t *d_occ8 = nullptr, *d_inv2 = nullptr;
-    uint32_t *d_kocc = nullptr, *d_kr3 = nullptr, *d_kbstart = nullptr;
-    uint64_t *d_kocc8 = nullptr, *d_kinv2 = nullptr;
+    DflKRec *d_krec = nullptr;
+    uint32_t *d_kbstart = nullptr;
+    uint64_t *d_kinv2 = nullptr;
     uint32_t *d_sym = nullptr, *d_pos = nullptr, *d_rhist = nullptr, *d_status = nullptr, *d_chk = nullptr;
     uint64_t *d_cumbits = nullptr;
     DflJob *d_jobs = nullptr; size_t jobs_cap = 0;
@@ -81,7 +82,7 @@ void dfl_destroy(void *v)
     if (!s) return;
     (void)hipSetDevice(s->device);
     dfree(s->d_seq); dfree(s->d_occ); dfree(s->d_occ8); dfree(s->d_inv2); dfree(s->d_bstart);
-    dfree(s->d_kocc); dfree(s->d_kr3); dfree(s->d_kbstart); dfree(s->d_kocc8); dfree(s->d_kinv2); dfree(s->d_sym); dfree(s->d_pos);
+    dfree(s->d_krec); dfree(s->d_kbstart); dfree(s->d_kinv2); dfree(s->d_sym); dfree(s->d_pos);
     dfree(s->d_rhist); dfree(s->d_status); dfree(s->d_cumbits); dfree(s->d_jobs); dfree(s->d_out);
     dfree(s->d_seg_sym); dfree(s->d_seg_pos); dfree(s->d_seg_cnt); dfree(s->d_chk);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -112,7 +113,7 @@ DflTables make_tables(const DflState *s, const SnkSeqView &v, int level)
     T.bytes = v.d_bytes; T.seq = s->d_seq; T.occ = s->d_occ; T.occ8 = s->d_occ8; T.inv2 = s->d_inv2; T.bstart = s->d_bstart;
     T.sym = s->d_sym; T.pos = s->d_pos; T.cumbits = s->d_cumbits; T.rhist = s->d_rhist; T.status = s->d_status;
     T.seg_sym = s->d_seg_sym; T.seg_pos = s->d_seg_pos; T.seg_cnt = s->d_seg_cnt;
-    T.k_occ = s->d_kocc; T.k_r3 = s->d_kr3; T.k_bstart = s->d_kbstart; T.k_occ8 = s->d_kocc8; T.k_inv2 = s->d_kinv2;
+    T.k_rec = s->d_krec; T.k_bstart = s->d_kbstart; T.k_inv2 = s->d_kinv2;
     T.chk = s->d_chk;
     T.norestart = v.dfl_norestart ? 1u : 0u;
     T.use_k = (v.dfl_kmer && level == 9 && s->kindexed) ? 1u : 0u;   // pays off only for the 4096-member budget
@@ -302,19 +303,18 @@ int dfl_build_kindex(snk_ctx *c, DflState *s, const SnkSeqView &v)
     uint64_t itot = 0;
     uint32_t maxlen = 0;
     for (const DflSeq &q : s->seq) { itot += (uint64_t)q.len + 1u; maxlen = std::max(maxlen, q.len); }
-    DCHK(c, hipMalloc((void **)&s->d_kocc, itot * 4));
-    DCHK(c, hipMalloc((void **)&s->d_kr3, itot * 4));
-    DCHK(c, hipMalloc((void **)&s->d_kocc8, itot * 8));
+    DCHK(c, hipMalloc((void **)&s->d_krec, itot * sizeof(DflKRec)));
     DCHK(c, hipMalloc((void **)&s->d_kinv2, itot * 8));
     DCHK(c, hipMalloc((void **)&s->d_kbstart, n * 65537u * 4));
-    uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
-    DevTemps temps; temps.own(d_key); temps.own(d_skey); temps.own(d_val); temps.own(d_tmp);
+    uint16_t *d_key = nullptr, *d_skey = nullptr; uint32_t *d_val = nullptr, *d_kocc = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    DevTemps temps; temps.own(d_key); temps.own(d_skey); temps.own(d_val); temps.own(d_kocc); temps.own(d_tmp);
     const size_t cap = (size_t)maxlen + 1u;
     DCHK(c, hipMalloc((void **)&d_key, cap * 2));
     DCHK(c, hipMalloc((void **)&d_skey, cap * 2));
     DCHK(c, hipMalloc((void **)&d_val, cap * 4));
+    DCHK(c, hipMalloc((void **)&d_kocc, cap * 4));            // one sequence's positions by bucket (the records take them over)
     {
-        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_skey, d_val, s->d_kocc, (int)cap, 0, 16, v.stream);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_skey, d_val, d_kocc, (int)cap, 0, 16, v.stream);
         if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort sizing failed");
     }
     DCHK(c, hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
@@ -326,14 +326,14 @@ int dfl_build_kindex(snk_ctx *c, DflState *s, const SnkSeqView &v)
         if (m6) {
             const uint32_t grid = std::min<uint32_t>((m6 + 255u) / 256u, 4096u);
             hipLaunchKernelGGL(dfl_khash_kernel, dim3(grid), dim3(256), 0, v.stream, v.d_bytes + q.boff, m6, d_key, d_val);
-            hipError_t e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_skey, d_val, s->d_kocc + q.ioff, (int)m6, 0, 16, v.stream);
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_skey, d_val, d_kocc, (int)m6, 0, 16, v.stream);
             if (e != hipSuccess) return snk_internal_fail(c, SNK_E_HIP, "radix sort failed");
         }
         hipLaunchKernelGGL(dfl_kbstart_kernel, dim3((65537u + 255u) / 256u), dim3(256), 0, v.stream, d_skey, m6, kbst);
         if (m6) {
             const uint32_t grid = std::min<uint32_t>((m6 + 255u) / 256u, 4096u);
-            hipLaunchKernelGGL(dfl_kinv_kernel, dim3(grid), dim3(256), 0, v.stream, s->d_kocc + q.ioff, d_skey, kbst,
-                               v.d_bytes + q.boff, s->d_inv2 + q.ioff, m6, s->d_kinv2 + q.ioff, s->d_kocc8 + q.ioff, s->d_kr3 + q.ioff);
+            hipLaunchKernelGGL(dfl_kinv_kernel, dim3(grid), dim3(256), 0, v.stream, d_kocc, d_skey, kbst,
+                               v.d_bytes + q.boff, s->d_inv2 + q.ioff, m6, s->d_kinv2 + q.ioff, s->d_krec + q.ioff);
         }
     }
     DCHK(c, hipGetLastError());
@@ -354,7 +354,7 @@ int dfl_prepare(snk_ctx *c, int level, SnkSeqView &v, DflState *&s)
     if (!s->indexed) { rc = dfl_build_index(c, s, v); if (rc != SNK_OK) { dfl_drop(c); s = nullptr; return rc; } }
     if (level == 9 && v.dfl_kmer && !s->kindexed) {
         rc = dfl_build_kindex(c, s, v);
-        if (rc != SNK_OK) { dfree(s->d_kocc); dfree(s->d_kr3); dfree(s->d_kocc8); dfree(s->d_kinv2); dfree(s->d_kbstart); return rc; }
+        if (rc != SNK_OK) { dfree(s->d_krec); dfree(s->d_kinv2); dfree(s->d_kbstart); return rc; }
     }
     if (s->level == level) return SNK_OK;
     // stand-alone stream of every sequence at this level

@@ -18,6 +18,9 @@ constexpr uint32_t DFL_HIST = 320u;            // 0..285 literal/length codes, 2
 constexpr uint32_t DFL_DOFF = 288u;
 constexpr uint32_t DFL_HEAP = 573u;            // 2 * L_CODES + 1
 constexpr uint32_t DFL_WAVES = 4u;             // wavefronts per workgroup
+#ifndef DFL_KW
+#define DFL_KW 16u                               // bucket members the K-pass looks at first (then 64 at a time)
+#endif
 
 // LDS of a workgroup (bytes): per wavefront its symbol histogram; ONE set of the LDS tree-building arrays, used
 // only by blocks with more than 64 distinct literal/length symbols (binary data) and taken under a lock -- DNA
@@ -60,6 +63,14 @@ constexpr uint32_t DFL_SEG_SLACK = 2048u;      // a segment runs this far into t
 constexpr uint32_t DFL_ST_CAP = 2u;           // status bit: a stored symbol stream ran beyond its capacity
 constexpr uint32_t DFL_SEG_ROOM = 300u;        // scratch entries beyond that (one match can carry the parser 258 further)
 
+// Member of a six-byte bucket: everything the K-pass reads about it, in one 16-byte load (three parallel arrays cost
+// three cache lines per group of candidates; the kernel is bound by the number of distinct lines it touches).
+struct __attribute__((aligned(16))) DflKRec {
+    uint64_t d8;              // the 8 bytes at the position
+    uint32_t v;               // the position
+    uint32_t r3;              // its rank in its 3-byte bucket
+};
+
 struct DflTables {
     const uint8_t *bytes;
     DflSeq *seq;
@@ -68,8 +79,9 @@ struct DflTables {
     const uint64_t *inv2;                    // per position: index in occ (low 32) | rank in its bucket (high 32)
     // second index, bucketed by a 16-bit hash of SIX bytes (positions <= len - 6): every chain member that
     // matches the probe in >= 6 bytes is in the probe's bucket
-    const uint32_t *k_occ, *k_r3, *k_bstart;  // position, its rank in the 3-byte bucket; k_bstart: 65537 per sequence
-    const uint64_t *k_occ8, *k_inv2;          // the 8 bytes there; per position: index in k_occ | rank in its bucket
+    const DflKRec *k_rec;                     // by six-byte bucket, positions ascending: one 16-byte record per member
+    const uint32_t *k_bstart;                 // 65537 bucket bounds per sequence
+    const uint64_t *k_inv2;                   // per position: index in k_rec | rank in its bucket << 32
     uint32_t use_k;
     uint32_t norestart;                       // option "deflate_norestart": pair jobs parse x from its start (testing)
     uint32_t *sym, *pos;
@@ -143,7 +155,7 @@ __global__ void dfl_kbstart_kernel(const uint16_t *skey, uint32_t m, uint32_t *b
 }
 
 __global__ void dfl_kinv_kernel(const uint32_t *kocc, const uint16_t *skey, const uint32_t *kbstart, const uint8_t *b,
-                                const uint64_t *inv2, uint32_t m, uint64_t *kinv2, uint64_t *kocc8, uint32_t *kr3)
+                                const uint64_t *inv2, uint32_t m, uint64_t *kinv2, DflKRec *krec)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -151,8 +163,9 @@ __global__ void dfl_kinv_kernel(const uint32_t *kocc, const uint16_t *skey, cons
     for (; i < m; i += stride) {
         const uint32_t p = kocc[i];
         kinv2[p] = (uint64_t)i | ((uint64_t)(i - kbstart[skey[i]]) << 32);
-        kocc8[i] = ((const U64 *)(b + p))->v;
-        kr3[i] = (uint32_t)(inv2[p] >> 32);
+        DflKRec r;
+        r.d8 = ((const U64 *)(b + p))->v; r.v = p; r.r3 = (uint32_t)(inv2[p] >> 32);
+        krec[i] = r;
     }
 }
 
@@ -880,8 +893,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
     const uint64_t *occ8x = T.occ8 + sx.ioff, *occ8y = T.occ8 + sy.ioff;
     const uint64_t *inv2x = T.inv2 + sx.ioff, *inv2y = T.inv2 + sy.ioff;
     const uint32_t *kbsx = T.k_bstart + (size_t)job.xi * 65537u;
-    const uint32_t *koccx = T.k_occ + sx.ioff, *koccy = T.k_occ + sy.ioff, *kr3x = T.k_r3 + sx.ioff, *kr3y = T.k_r3 + sy.ioff;
-    const uint64_t *kocc8x = T.k_occ8 + sx.ioff, *kocc8y = T.k_occ8 + sy.ioff;
+    const DflKRec *krecx = T.k_rec + sx.ioff, *krecy = T.k_rec + sy.ioff;
     const uint64_t *kinv2x = T.k_inv2 + sx.ioff, *kinv2y = T.k_inv2 + sy.ioff;
 
     // the two seam positions whose 3-byte hash mixes x and y
@@ -999,7 +1011,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                     const bool p_in_y = p >= lx;
                     // the bucket holds every earlier position of the sequence with this hash, the window only the
                     // most recent few (about 8 on DNA): look at 16 first, then 64 at a time
-                    uint32_t width = 16u;
+                    uint32_t width = DFL_KW;
                     for (uint32_t j0 = 0; j0 < ktotal; j0 += width, width = 64u) {
                         const uint32_t j = j0 + lane;
                         const bool in = j < ktotal && lane < width;
@@ -1008,9 +1020,8 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                         uint64_t d8 = 0;
                         if (in) {
                             const uint32_t idx = fromy ? kybase - j : kxtop - (j - kny);
-                            v = (fromy ? koccy : koccx)[idx];
-                            d8 = (fromy ? kocc8y : kocc8x)[idx];
-                            r3 = (fromy ? kr3y : kr3x)[idx];
+                            const DflKRec r = (fromy ? krecy : krecx)[idx];
+                            v = r.v; d8 = r.d8; r3 = r.r3;
                         }
                         const uint32_t q = fromy ? lx + v : v;
                         // position of q in the 3-byte chain of p (0 = its head)
@@ -1217,8 +1228,10 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
     }
 }
 
-// The two kernels: with the six-byte index (gzip) the body needs a few more registers and runs best at 7 waves per
-// SIMD; without it (zlib) at 8.  (Measured: 6 / 7 / 8 waves -> gzip 126 / 133 / 118 k, zlib 140 / 153 / 158 k pair-compr/s.)
+// The two kernels: with the six-byte index (gzip) the body needs a few more registers and runs at 7 waves per SIMD;
+// without it (zlib) at 8.  Measured, pair-compr/s at 1024 x 1 Mbp: gzip 4 / 5 / 6 / 7 waves 138 / 167 / 167 / 170 k --
+// beyond 5 waves the kernel is bound by the memory system (distinct lines per probe), not by latency; zlib 4 / 5 / 8
+// waves 139 / 139 / 167 k.  The K-pass looks at 16 bucket members first (8: 153 k, 12: 164 k, 16: 167 k at 5 waves).
 #ifndef DFL_WPE_K
 #define DFL_WPE_K 7
 #endif
