@@ -67,7 +67,7 @@ struct snk_ctx_impl {
     // deflate add-on (snk_deflate.hip): opaque state + its destructor
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
     bool dfl_serial = false, dfl_kmer = true, dfl_norestart = false;
-    uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_zero = nullptr;
+    uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_pmask = nullptr, *d_zero = nullptr;
     const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
@@ -105,7 +105,7 @@ template <typename T> void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p =
 
 void free_sequences(snk_ctx_impl *c)
 {
-    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
+    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_pmask); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
     dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0;
     dfree(c->d_exc_runs); dfree(c->d_exc_roff);
@@ -144,7 +144,7 @@ bool build_luts(std::vector<uint16_t> &slot, std::vector<uint32_t> &hash)
 SnkTables make_tables(const snk_ctx_impl *c)
 {
     SnkTables T;
-    T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.packed_off = c->d_packed_off; T.len = c->d_len;
+    T.bytes = c->d_bytes_ptr; T.bytes_arena = c->d_bytes; T.bytes_off = c->d_bytes_off; T.packed_arena = c->d_packed; T.mask_arena = c->d_pmask; T.packed_off = c->d_packed_off; T.len = c->d_len;
     T.snap_pos = c->d_snap_pos; T.snap_out = c->d_snap_out;
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
     T.exc_runs = c->d_exc_runs; T.exc_roff = c->d_exc_roff;
@@ -727,6 +727,17 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 2048);
         hipLaunchKernelGGL(snk_pack_kernel, dim3(grid), dim3(256), 0, c->stream,
                            c->d_bytes + boff[g], (uint64_t)lens[g], c->d_packed + poff[g]);
+    }
+    if (c->any_exc) {                 // the mask arena: where the bytes of the 2-bit sequences are not ACGT
+        HIPCHK(c, hipMalloc((void **)&c->d_pmask, ptot));
+        HIPCHK(c, hipMemsetAsync(c->d_pmask, 0, ptot, c->stream));
+        for (size_t g = 0; g < n; ++g) {
+            if (!c->is_packed[g] || !c->has_exc[g]) continue;
+            uint64_t nb = ((uint64_t)lens[g] + 3) / 4;
+            uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 2048);
+            hipLaunchKernelGGL(snk_packmask_kernel, dim3(grid), dim3(256), 0, c->stream,
+                               c->d_bytes + boff[g], (uint64_t)lens[g], c->d_pmask + poff[g]);
+        }
     }
     HIPCHK(c, hipGetLastError());
 

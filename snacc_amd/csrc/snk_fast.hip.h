@@ -102,6 +102,8 @@ struct SnkFastLane {
     bool ron_y;                            // ... which sequence that is
     uint32_t *ovf;                         // this chain's overflow table
     uint32_t xlim;                         // first position >= the last scan whose window is not clean
+    uint32_t mask_until;                   // cursors below this may read a table entry whose window holds an exception: the
+                                           // steady loop then runs with the mask window (see "Exceptions" below)
 };
 
 // diagnostic build only (-DSNK_STATS, `make stats`): event counters of the exception machinery (tools/gpu_exc.py) and a
@@ -120,14 +122,18 @@ __device__ unsigned long long snk_stats[32];
 // =========================================================================
 // A position p is CLEAN when its window [p-4, p+12) lies inside one sequence, >= 4 bases from the
 // stream start, and its 16-base granule is not flagged (no exception within the window, by the
-// dilation of the flags).  The steady loop only ever probes and inserts clean positions: 5-mer,
-// hash and the 2-bit compare are then exactly what liblz4 sees on the bytes.  Everything else goes
-// through the byte-accurate general path below: hash of the real 5 bytes; if an ACGT 5-mer has
-// that hash the slot of the 2-bit table is used -- with the offset when the inserted position is
-// clean, else with the sentinel 0xFFFF and the absolute position in the chain's overflow table
-// ovf[hash] -- otherwise only ovf[hash] (liblz4's own table restricted to the non-ACGT hashes).
-// A steady-loop probe that reads a sentinel leaves through the service exit; aging treats a
-// sentinel like any other entry (an entry older than one block is dead whatever it points to).
+// dilation of the flags).  The steady loop only ever probes and inserts at clean CURSOR positions:
+// 5-mer and hash are then exactly what liblz4 sees on the bytes.  Every other cursor position goes
+// through the byte-accurate general path below: hash of the real 5 bytes; if an ACGT 5-mer has that
+// hash the slot of the 2-bit table takes the position (as an ordinary 16-bit offset), otherwise
+// ovf[hash] does (the chain's overflow table: liblz4's own table restricted to the non-ACGT hashes).
+// CANDIDATES may be anywhere: beside the packed arena lies a mask arena of the same layout (2 bits per
+// base, 11 where the byte is not one of ACGT), and the steady loop ORs the candidate's mask window
+// into the difference of the 2-bit windows: an exception in the candidate window ends the match
+// there, exactly as the byte compare does (the cursor window holds ACGT only, an exception byte
+// equals none of them).  Round 2's first version wrote a sentinel instead of the offset when the
+// inserted position was not clean; the ~3.5 service exits per lane and site that the later reads
+// of those sentinels cost were most of a site's price.
 __device__ __forceinline__ bool snk_exc_clean(const SnkFastLane &L, uint32_t p)
 {
     const uint32_t lx = L.s.lx;
@@ -195,10 +201,8 @@ __device__ __forceinline__ void snk_exc_put(SnkFastLane &L, const SnkTables &T, 
 {
     const uint32_t s = T.lut_h2s[h];
     if (s != 0xFFFFu) {
-        const bool cl = snk_exc_clean_near(L, pos);                 // (every put is at or just behind the cursor)
-        tbl[s] = cl ? (uint16_t)(pos - L.base) : (uint16_t)0xFFFFu;
+        tbl[s] = (uint16_t)(pos - L.base);                          // (<= 65 527: puts end 12 bytes before the block does)
         atomicOr(&bm[s >> 5], 1u << (s & 31u));
-        if (!cl) { L.ovf[h] = pos; SNK_COUNT(6); }
     } else {
         SNK_COUNT(7);
         L.ovf[h] = pos;
@@ -211,11 +215,9 @@ __device__ __forceinline__ uint32_t snk_exc_get(const SnkFastLane &L, const SnkT
     const uint32_t s = T.lut_h2s[h];
     if (s != 0xFFFFu) {
         const uint32_t e = tbl[s];
-        if (e != 0xFFFFu) {
-            const bool iscur = ((bm[s >> 5] >> (s & 31u)) & 1u) != 0u;
-            valid = iscur | (e > cur - L.base);
-            return L.base + e - (iscur ? 0u : 65536u);
-        }
+        const bool iscur = ((bm[s >> 5] >> (s & 31u)) & 1u) != 0u;
+        valid = iscur | (e > cur - L.base);
+        return L.base + e - (iscur ? 0u : 65536u);
     }
     const uint32_t cand = L.ovf[h];
     valid = cand + SNK_MAXDIST >= cur;
@@ -290,7 +292,6 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             uint32_t *dst = T.snap_fast + (size_t)L.xi * SNK_FSLOTS;
             for (uint32_t t = 0; t < SNK_FSLOTS; ++t) {
                 uint32_t v = ((bm[t >> 5] >> (t & 31u)) & 1u) ? (L.base + tbl[t]) : 0u;
-                if (EXC && v != 0u && tbl[t] == 0xFFFFu) v = t < 894u ? L.ovf[T.lut_s2h[t]] : 0u;   // sentinel: the position is in the overflow table
                 dst[t] = v;
             }
             if (EXC) {      // liblz4's whole table (what a byte kernel, or another chain with exceptions, starts from)
@@ -328,6 +329,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         if (EXC) {
             snk_exc_seek(L, L.pos);
+            if (!snk_exc_clean(L, L.pos)) L.mask_until = L.pos + 65536u;      // (an entry is read at most 65 535 bytes further on)
             snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, L.pos)), L.pos);
         } else {
             const uint32_t w0 = snk_fetch32(L.s, L.pos);
@@ -407,6 +409,9 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
         SNK_COUNT(1);
         snk_exc_seek(L, cur);
+        // the positions put below may have an exception in their windows (by the granule flags: a superset): the steady
+        // loop then compares with the mask window for as long as such an entry can be read (65 535 bytes)
+        if (!snk_exc_clean(L, cur) || (L.pending && !snk_exc_clean(L, cur - 2u))) { L.mask_until = cur + 65536u; SNK_COUNT(6); }
         if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
         const uint32_t h = snk_hash5(snk_ld8(L.g, cur));
         bool valid;
@@ -525,8 +530,11 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_lshrrev_b32_e32 v104, 2, %[t]\n\t" \
     "v_add_u32_e32 v104, v104, %[yoffB]\n\t"
 // shadow of the candidate load: commit of the previous probe, refill, validity (PH = phase register)
-#define SNK_STEADY_SHADOW(PH) \
-    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
+#define SNK_STEADY_SHADOW(PH) SNK_STEADY_SHADOW_X(PH, "")
+// (instantiations for sequences with exceptions: the candidate's mask window, same offset in the mask arena)
+#define SNK_STEADY_MASKLOAD "global_load_dwordx2 v[118:119], v104, %[marena]\n\t"
+#define SNK_STEADY_SHADOW_X(PH, LOAD2) \
+    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" LOAD2 \
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
     "global_load_dword v108, %[nxoff], %[arena]\n\t" SNK_PADC \
@@ -544,21 +552,16 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_cmp_gt_u32_e32 vcc, 15, v100\n\t" \
     "s_and_b64 %[ss], vcc, %[sv]\n\t" \
     "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
-// instantiations for sequences with exceptions: a table entry 0xFFFF (v91) is a sentinel -- the position is in
-// the chain's overflow table -- and trips the limit test like a straddling window
-#define SNK_STEADY_SENTINEL_DUAL \
-    "v_cmp_eq_u32_e32 vcc, 0xffff, v91\n\t" \
-    "s_or_b64 %[ss], %[ss], vcc\n\t" \
-    "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
-#define SNK_STEADY_SENTINEL_YONLY \
-    "v_cmp_eq_u32_e32 vcc, 0xffff, v91\n\t" \
-    "s_mov_b64 %[ss], vcc\n\t" \
-    "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
 // compare, next cursor, next window + LUT reads, accounting, exit test (LIM = limit register)
-#define SNK_STEADY_REST(LIM) \
+#define SNK_STEADY_REST(LIM) SNK_STEADY_REST_X(LIM, "")
+// (exceptions: the mask window ORed into the difference -- an exception in the candidate window ends the match there)
+#define SNK_STEADY_MASKOR \
+    "v_alignbit_b32 v119, v119, v118, v109\n\t" \
+    "v_or_b32_e32 v113, v113, v119\n\t"
+#define SNK_STEADY_REST_X(LIM, MASKOR) \
     "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
-    "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
+    "v_xor_b32_e32 v113, v113, %[wc]\n\t" MASKOR \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
     "v_ffbl_b32_e32 v114, v114\n\t" \
     "v_and_b32_e32 v114, v114, v110\n\t" \
@@ -599,7 +602,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st) \
     : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
       [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
-      [arena] "s"(arena) \
+      [arena] "s"(arena), [marena] "s"(marena) \
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
@@ -639,8 +642,8 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 // ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
 template <bool ASM, bool EXC>
-__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm, const uint16_t *slot, uint32_t lds_off,
-                                                uint32_t round_bases)
+__device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, snk_g8 *const marena, uint16_t *tbl, uint32_t *bm,
+                                                const uint16_t *slot, uint32_t lds_off, uint32_t round_bases)
 {
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
 #ifdef SNK_STATS
@@ -664,6 +667,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     if (EXC) lim_abs = lim_abs < L.xlim ? lim_abs : L.xlim;       // ... the cursor window must stay clean
     if (EXC && round_bases != 0xFFFFFFFFu && lim_abs - L.cur > round_bases) lim_abs = L.cur + round_bases;   // a short round
     const uint32_t limc = lim_abs - vb;                           // next probe position >= limc: service
+    // (EXC, wave-uniform) can a lane of this run read an entry whose window holds an exception?  Only then the mask window is loaded.
+    const bool need_mask = EXC && __any(L.cur < L.mask_until);
     const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
 
     uint32_t c = L.cur - vb, anchor_c = L.anchor - vb, op = L.op;
@@ -695,7 +700,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
         // every lane's block wholly > 64 KiB past its seam (no t can land in x or on the seam)?
-        if (!EXC) {
+        if (!EXC || !need_mask) {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
                              SNK_STEADY_OPERANDS);
@@ -704,11 +709,11 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
                              SNK_STEADY_OPERANDS);
         } else {
             if (__all(sx + 15 <= 0))
-                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_SENTINEL_YONLY SNK_STEADY_REST("v105")
-                             SNK_STEADY_OPERANDS);
+                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW_X("%[t]", SNK_STEADY_MASKLOAD)
+                             SNK_STEADY_REST_X("%[limc]", SNK_STEADY_MASKOR) SNK_STEADY_OPERANDS);
             else
-                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW("v103") SNK_STEADY_STRADDLE SNK_STEADY_SENTINEL_DUAL
-                             SNK_STEADY_REST("v105") SNK_STEADY_OPERANDS);
+                asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW_X("v103", SNK_STEADY_MASKLOAD) SNK_STEADY_STRADDLE
+                             SNK_STEADY_REST_X("v105", SNK_STEADY_MASKOR) SNK_STEADY_OPERANDS);
         }
         c = lit + anchor_c;                                           // the loop keeps the NEXT cursor in c
         valid = t > c;
@@ -734,9 +739,14 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         const bool straddle = valid & ((uint32_t)((int32_t)t - sx) < 15u);
         const uint32_t lit = c - anchor_c;
         const uint32_t wd = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, 2u * (tt & 3u));
+        uint32_t wm = 0u;                                         // (EXC) the candidate's mask window: 11 where a byte is not one of ACGT
+        if (EXC && need_mask) {
+            const uint64_t mv = snk_ld8g(marena + (size_t)((inx ? xoffB : yoffB) + (tt >> 2)));
+            wm = __builtin_amdgcn_alignbit((uint32_t)(mv >> 32), (uint32_t)mv, 2u * (tt & 3u));
+        }
 
         // ---- compare, next cursor ----
-        const uint32_t x = wc ^ wd;
+        const uint32_t x = (wc ^ wd) | wm;
         const uint32_t r = snk_ffbl(x >> 8);                      // 2 * equal bases from cur; 0xFFFFFFFF: all 12
         const bool m = valid & (r >= 8u);
         const uint32_t e2 = c + (r >> 1);                         // all 12 equal: huge; past the match limit: >= limc -> service
@@ -758,7 +768,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         // service: literal run >= 15, back-extension reaches 4 (may go on), output budget near
         int32_t mx = (int32_t)(b + 11u) > (int32_t)lit ? (int32_t)(b + 11u) : (int32_t)lit;
         { const int32_t z = (int32_t)op - olimZ + 14; mx = mx > z ? mx : z; }       // op before this probe > olimit - 70
-        const bool svc = (mx >= 15) | (ncur >= limc) | straddle | (EXC && e == 0xFFFFu);       // sentinel: position in the overflow table
+        const bool svc = (mx >= 15) | (ncur >= limc) | straddle;
         SNK_TRACE_REC(3u, vb + c, (uint32_t)(T0 + (int32_t)t), (r << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), vb + c);
 #ifdef SNK_STATS
         if (stat_first) SNK_COUNT(15);
@@ -789,16 +799,14 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     if (EXC) {
         const uint32_t cur = vb + c;
         uint32_t cand = (uint32_t)(T0 + (int32_t)t);
-        if ((t & 0xFFFFu) == 0xFFFFu) {                           // sentinel read: the candidate is in the overflow table
+        if (valid && !snk_exc_clean(L, cand)) {                   // an exception near the candidate: the real bytes decide
             SNK_COUNT(2);
-            cand = L.ovf[snk_hash5(snk_ld8(L.g, cur))];
-            valid = cand + SNK_MAXDIST >= cur;
-            snk_exc_finish(L, cur, cand, valid);                  // ... and not clean: the real bytes decide
+            snk_exc_finish(L, cur, cand, valid);
         } else {
-            // Cursor and candidate windows are clean (the loop's invariant; only clean positions get an offset in
-            // the table), so the 2-bit windows -- hot in the L1 -- decide the ordinary cases exactly as the loop
-            // would; a match that may run on beyond them (back-extension 4, 12 bases forward, budget, block end)
-            // is counted on the real bytes, which may hold an exception a little further on.
+            // Cursor and candidate windows are clean here, so the 2-bit windows -- hot in the L1 -- decide the
+            // ordinary cases exactly as the loop would; a match that may run on beyond them (back-extension 4,
+            // 12 bases forward, budget, block end) is counted on the real bytes, which may hold an exception a
+            // little further on.
             const uint32_t wc2 = snk_fetch32(L.s, cur);
             const uint32_t wd2 = snk_fetch32(L.s, valid ? cand : cur);
             const uint32_t x2 = wc2 ^ wd2;
@@ -957,25 +965,13 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                 // offsets from the virtual base of the block before spos (k3 = -lx mod 4, see snk_fast_steady)
                 const uint32_t k3 = (0u - T.len[xi]) & 3u;
                 const uint32_t pvb = spos - 65536u - k3;
-                // (EXC) a snapshot position whose window is not clean gets the sentinel: the chain's overflow table,
-                // filled from the sequence's full snapshot below, holds it
-                const uint32_t xlen = T.len[xi];
-                const uint32_t *xfl = (EXC && T.exc_off[xi] != 0xFFFFFFFFu) ? T.exc_flags + T.exc_off[xi] : nullptr;
                 for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
                     uint32_t v = k3 * 0x10001u;                       // stream start: every slot holds position 0
                     if (use) {
                         const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
                         uint32_t lo = (a0 != 0u && a0 + 65536u >= spos) ? a0 - pvb : 0u;   // previous block, else dead
                         uint32_t hi = (a1 != 0u && a1 + 65536u >= spos) ? a1 - pvb : 0u;
-                        if (EXC) {
-                            // (snapshot positions are >= spos - 65536 >= 0 and inside x; a0 >= 4 unless the stream is young)
-                            const uint32_t g0 = a0 < 4u ? 0u : (a0 - 4u) >> 4, g1 = a1 < 4u ? 0u : (a1 - 4u) >> 4;
-                            if (lo && !(a0 + 12u <= xlen && !(xfl && ((xfl[g0 >> 5] >> (g0 & 31u)) & 1u)))) lo = 0xFFFFu;
-                            if (hi && !(a1 + 12u <= xlen && !(xfl && ((xfl[g1 >> 5] >> (g1 & 31u)) & 1u)))) hi = 0xFFFFu;
-                        }
                         v = lo | (hi << 16);
-                    } else if (EXC && (xlen < 12u || (xfl && (xfl[0] & 1u)))) {
-                        v = 0xFFFFFFFFu;                              // position 0 is not clean: sentinel, the overflow table (all zero) holds it
                     }
                     ((uint32_t *)dst)[t] = v;
                 }
@@ -1000,6 +996,8 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                     L.ry = L.fy ? T.exc_runs + 2u * T.exc_roff[job.yi] : nullptr;
                     L.ri = 0u; L.ron_y = false;
                     L.xlim = 0u;
+                    // the start state (position 0 in every slot, or x's prefix snapshot) may point at exceptions of x
+                    L.mask_until = L.fx ? L.pos + 65536u : 0u;
                 }
             }
             const uint32_t asked = (uint32_t)__builtin_popcountll(mask);
@@ -1065,7 +1063,8 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
         const bool company = EXC && __any(waiting != 0u);        // wave-uniform: someone waits at a site: a short round
         if (have && !parked && waiting == 0u)
-            snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, tbl, bm, slot, mine_off, company ? 1000u : 0xFFFFFFFFu);
+            snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm, slot, mine_off,
+                                      company ? 1000u : 0xFFFFFFFFu);
     }
 }
 

@@ -69,6 +69,23 @@ __global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packe
     }
 }
 
+// The mask arena of the 2-bit kernel (sequences with exceptions): same layout as the packed bytes, 11 where the byte
+// is not one of ACGT, 00 elsewhere and behind the end.
+__global__ void snk_packmask_kernel(const uint8_t *bytes, uint64_t n, uint8_t *mask)
+{
+    uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nbytes = (n + 3) >> 2;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; o < nbytes; o += stride) {
+        uint32_t v = 0;
+        for (uint32_t b = 0; b < 4u; ++b) {
+            const uint64_t i = o * 4 + b;
+            if (i < n) { const uint8_t c = bytes[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) v |= 3u << (2u * b); }
+        }
+        mask[o] = (uint8_t)v;
+    }
+}
+
 // Which of liblz4's 4096 hash values occur inside one sequence (5 bytes at every position p <= n-5).
 // One 4096-bit set per launch target, OR-ed into `set` (128 words).
 __global__ void snk_hashset_kernel(const uint8_t *bytes, uint64_t n, uint32_t *set)

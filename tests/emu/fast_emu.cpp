@@ -70,7 +70,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         spos[g] = lens[g] > SNK_BLOCK ? (uint32_t)(lens[g] / SNK_BLOCK * SNK_BLOCK) : 0u;
     }
     ptot += SNK_ARENA_SLACK;
-    std::vector<uint8_t> arena(ptot, 0), bytes(btot + SNK_PAD, 0), zero(4 * SNK_PAD, 0);
+    std::vector<uint8_t> arena(ptot, 0), marena(ptot, 0), bytes(btot + SNK_PAD, 0), zero(4 * SNK_PAD, 0);
     std::vector<uint32_t> fl(ftot + 1, 0);
     {
         size_t f = 0;
@@ -81,6 +81,8 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
             if (!ok[g]) continue;
             for (uint64_t i = 0; i < lens[g]; ++i)
                 arena[poff[g] + (i >> 2)] |= (uint8_t)(((seqs[g][i] >> 1) & 3u) << (2u * (i & 3u)));
+            for (uint64_t i = 0; i < lens[g]; ++i)
+                if (!acgt(seqs[g][i])) marena[poff[g] + (i >> 2)] |= (uint8_t)(3u << (2u * (i & 3u)));
         }
     }
     std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), snap_gen((size_t)n * 4096, 0), status(1, 0);
@@ -101,7 +103,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
 
     SnkTables T;
     memset(&T, 0, sizeof T);
-    T.packed_arena = arena.data(); T.packed_off = poff.data(); T.len = len.data();
+    T.packed_arena = arena.data(); T.mask_arena = marena.data(); T.packed_off = poff.data(); T.len = len.data();
     T.bytes_arena = bytes.data(); T.bytes_off = boff.data(); T.zero_pad = zero.data();
     T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data(); T.snap_gen = snap_gen.data();
     T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.header_bytes = header_bytes;

@@ -43,6 +43,9 @@ for kind in ("pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac1
         st = (ctypes.c_ulonglong * 32)()
         L_.snk_debug_stats(st)
         names = ["steady exits", "general probes", "sentinel reads", "flushes", "byte matches", "site arrivals", "sentinel puts", "ovf-only puts"]
-        print("   stats (upload + 4 launches):", {nm: int(st[i]) for i, nm in enumerate(names)})
+        print("   stats (upload + 4 launches):", {nm: int(st[i]) for i, nm in enumerate(names) if i != 7})
+        if st[14]:
+            print(f"   wave cycles {int(st[7]):,}: in the loop {st[13] / st[7]:.1%}, loop entries {int(st[14]):,}, per entry: outside {(st[7] - st[13]) / st[14]:,.0f} cycles"
+                  f" (finish {st[24] / st[14]:,.0f}, general rounds {st[25] / st[14]:,.0f} in {st[26] / st[14]:.2f} rounds)")
     print(f"{kind:18s} packed={ctx.num_packed}/{N} ms={best:.1f} pairs/s={rate:.0f} ({rate / ref * 100:.0f}% of pure) parity={ok}", flush=True)
     ctx.close()
