@@ -30,4 +30,5 @@ static inline uint32_t snk_emu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
 }
 #define __builtin_amdgcn_alignbit(hi, lo, sh) snk_emu_alignbit((hi), (lo), (sh))
 #define __builtin_amdgcn_sched_barrier(m) do { } while (0)
+#define __builtin_amdgcn_readlane(v, l) (v)
 #define __builtin_amdgcn_ballot_w64(p) ((unsigned long long)((p) ? 1ull : 0ull))
