@@ -33,6 +33,8 @@ struct snk_ctx_impl {
     int fast_dynamic = -1;           // -1 auto (by length spread), 0 static round robin, 1 atomic queue
     bool dense_tile = false;         // the last build_jobs found every pair of the tile fit for the 2-bit kernel
     hipEvent_t jobs_busy = nullptr;  // last launch that reads d_jobs: waited for before the list is rewritten
+    hipEvent_t ovf_busy = nullptr;   // last 2-bit launch with exceptions: its chains' overflow tables (one set per context) are
+    bool ovf_in_flight = false;      // in use until it ends -- the next such launch waits for it on its own stream
     std::string err;
 
     // options
@@ -60,7 +62,8 @@ struct snk_ctx_impl {
     std::vector<uint8_t> is_packed;  // goes to the 2-bit kernel: pure ACGT, or ACGT with a few exceptions
     std::vector<uint8_t> has_exc;    // ... the latter
     bool any_exc = false;
-    long exc_limit = 128;            // flagged 16-base granules per 2^20 bases up to which a sequence stays on the 2-bit kernel
+    long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (a quarter of
+                                     // them at 2048) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload)
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
     uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr;
@@ -107,7 +110,7 @@ void free_sequences(snk_ctx_impl *c)
 {
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_pmask); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
-    dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0;
+    dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0; c->ovf_in_flight = false;
     dfree(c->d_exc_runs); dfree(c->d_exc_roff);
     c->has_exc.clear(); c->any_exc = false;
     c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
@@ -227,12 +230,15 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             const size_t need = (size_t)grid * chains * 4096u * sizeof(uint32_t);       // one overflow table per resident chain
             if (need > c->ovf_bytes) {
                 HIPCHK(c, hipStreamSynchronize(st));
+                if (c->ovf_in_flight) { HIPCHK(c, hipEventSynchronize(c->ovf_busy)); c->ovf_in_flight = false; }
                 dfree(c->d_ovf);
                 HIPCHK(c, hipMalloc((void **)&c->d_ovf, need));
                 c->ovf_bytes = need;
                 T.ovf = c->d_ovf;
             }
         }
+        // (launches with exceptions share the context's overflow tables: one at a time, whatever their streams)
+        if (exc && c->ovf_in_flight) HIPCHK(c, hipStreamWaitEvent(st, c->ovf_busy, 0));
         if (exc && singles)
             hipLaunchKernelGGL(snk_fastx_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (exc && c->fast_asm)
@@ -246,6 +252,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         else
             hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
+        if (exc) { HIPCHK(c, hipEventRecord(c->ovf_busy, st)); c->ovf_in_flight = true; }
     }
     if (n_bytes && c->compact_ok) {
         const bool big = c->compact_cap == 2048;
@@ -459,6 +466,7 @@ int snk_ctx_create(int device, snk_ctx **out)
     CRCHK(hipSetDevice(device));
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRCHK(hipEventCreate(&c->jobs_busy));
+    CRCHK(hipEventCreateWithFlags(&c->ovf_busy, hipEventDisableTiming));
     {
         hipDeviceProp_t prop;
         CRCHK(hipGetDeviceProperties(&prop, device));
@@ -509,6 +517,7 @@ void snk_ctx_destroy(snk_ctx *c)
     dfree(c->d_jobs); dfree(c->d_out);
     for (auto &e : c->ev_log) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->jobs_busy) (void)hipEventDestroy(c->jobs_busy);
+    if (c->ovf_busy) (void)hipEventDestroy(c->ovf_busy);
     dfree(c->d_queue);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -658,10 +667,11 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
 
     // ---- which sequences go to the 2-bit kernel ------------------------------------------------------
     // Candidates by flagged granules; then the exact runs of exception bytes ("sites") from the caller's bytes of
-    // the flagged granules.  A site costs the wave about 1.5 % of a 1 Mbp pair (byte-accurate probes on cold ASCII
-    // lines + the service exits of the sentinel entries it leaves); the byte kernels run at 29 % (compact table,
-    // e.g. ACGT + N) down to 7 % (full table, e.g. ACGT + several IUPAC codes) of the 2-bit rate: a sequence stays on
-    // the 2-bit kernel up to 4 + 160 sites per 2^20 bases (measured: 100 sites per Mbp 43 %, tools/gpu_exc.py).
+    // the flagged granules.  Measured against pure ACGT (tools/gpu_exc.py, 1 Mbp genomes): 100 / 300 / 1000 / 3000
+    // scattered IUPAC codes per Mbp 75 / 58 / 37 / 20 %; 1 / 5 / 20 % lower case in runs of ~500 bases (soft-masked) 60 /
+    // 23 / 15 %.  The byte kernels such sequences would go to run at 29 % (compact table: ACGT + N only), 14 % (<= 2048
+    // distinct hashes) or 6 % (full table: several IUPAC codes, or soft-masked) of the 2-bit rate, so a sequence stays
+    // on the 2-bit kernel up to a quarter of its 16-base granules flagged and 4 + 2560 sites per 2^20 bases.
     c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false;
     std::vector<uint32_t> eoff(n, 0xFFFFFFFFu), runs, roff(n, 0);
     {

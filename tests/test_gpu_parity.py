@@ -271,6 +271,34 @@ def test_sequences_with_a_few_exceptions_stay_on_the_2bit_kernel(hip, oracle_mod
         assert np.array_equal(ctx.pairs(), exp_p[:7, :7])
 
 
+def test_soft_masked_genomes_stay_on_the_2bit_kernel(hip, oracle_mod):
+    """Lower-case stretches (soft-masked genomes) are runs of exceptions for the 2-bit kernel: up to a quarter of a
+    sequence's 16-base granules may be flagged by default.  Sizes equal the oracle's; both loops; next to a pure genome."""
+    o = oracle_mod
+    rng = np.random.default_rng(29)
+
+    def soft(a, pct, run=500):
+        a = a.copy()
+        for s0 in rng.integers(0, len(a) - run - 200, max(1, len(a) * pct // 100 // run)):
+            a[s0:s0 + int(rng.integers(run // 2, run * 3 // 2))] |= 0x20
+        return a
+
+    g = [o.lcg_genome(400 + k, n) for k, n in enumerate([300000, 200001, 131072, 150000, 262144])]
+    seqs = [soft(g[0], 5), soft(g[1], 15, 300), g[2], soft(g[3], 1), soft(o.lcg_mutant(g[0], 7), 8), soft(g[4], 3)]
+    seqs[1][:900] |= 0x20
+    seqs[3][-500:] |= 0x20
+    seqs[5][65300:66000] |= 0x20
+    exp_s = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    for opts in ({}, {"fast_asm": 0}, {"fast_lanes": 4, "fast_waves": 2}):
+        with hip.HipContext(0, **opts) as ctx:
+            ctx.upload(seqs)
+            assert ctx.num_packed == len(seqs)           # all on the 2-bit kernel
+            s, p = ctx.singles(), ctx.pairs()
+        assert np.array_equal(s, exp_s), (opts, np.flatnonzero(s != exp_s))
+        assert np.array_equal(p, exp_p), (opts, np.argwhere(p != exp_p)[:8].tolist())
+
+
 def test_related_genomes_same_ancestor(hip, oracle_mod):
     o = oracle_mod
     anc = o.lcg_genome(40, 180000)

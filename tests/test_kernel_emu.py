@@ -142,3 +142,27 @@ def test_emu_exceptions_fuzz(seed):
         seqs.append(_with_exceptions(rng, a, int(rng.integers(0, 4)), int(rng.integers(0, 8))))
     seqs.append(_with_exceptions(rng, oracle.lcg_mutant(seqs[0], 7) if set(bytes(seqs[0])) <= set(b"ACGT") else seqs[0].copy(), 1, 1))
     check(seqs, exc_limit=8192)
+
+
+def _soft_masked(rng, a, pct, run=500):
+    """Lower-case stretches of about `run` bases over `pct` % of an ACGT sequence (a soft-masked genome)."""
+    a = a.copy()
+    n = len(a)
+    for s0 in rng.integers(0, max(1, n - run - 200), max(1, n * pct // 100 // run)):
+        a[s0:s0 + int(rng.integers(run // 2, run * 3 // 2))] |= 0x20
+    return a
+
+
+def test_emu_soft_masked_stretches():
+    """Lower-case stretches are runs of exceptions: the general path walks through them on the real bytes, the table
+    entries it leaves are ordinary offsets, and the steady loop compares candidates near them through the mask window."""
+    rng = np.random.default_rng(23)
+    o = oracle
+    g = [o.lcg_genome(300 + k, n) for k, n in enumerate([180000, 140001, 131072, 90000])]
+    seqs = [_soft_masked(rng, g[0], 5), _soft_masked(rng, g[1], 20, 300), g[2], _soft_masked(rng, g[3], 2),
+            _soft_masked(rng, o.lcg_mutant(g[0], 5), 10)]
+    seqs[1][:700] |= 0x20                               # a stretch at the stream start
+    seqs[3][-400:] |= 0x20                              # ... and at the end (the seam of every pair with it in front)
+    seqs[0][65000:66100] |= 0x20                        # ... across a block edge
+    assert all(_packable(x, 65536) for x in seqs)       # (all of them run in the emulated kernel)
+    check(seqs, exc_limit=65536)

@@ -19,14 +19,22 @@ def variant(kind):
             s0 = int(rng.integers(0, L - 2000)); a[s0:s0 + 1000] = ord("N")
         if kind in ("iupac20", "n10x100+iupac20"):
             a[rng.integers(0, L, 20)] = rng.choice(np.frombuffer(b"RYKMSWN", dtype=np.uint8), 20)
-        if kind == "iupac100":
-            a[rng.integers(0, L, 100)] = rng.choice(np.frombuffer(b"RYKMSWN", dtype=np.uint8), 100)
+        if kind.startswith("soft"):                        # soft-masked: PCT % lower case in runs of about 500 bases
+            pct = int(kind[4:])
+            for s0 in rng.integers(0, L - 600, max(1, L * pct // 100 // 500)):
+                ln = int(rng.integers(300, 700))
+                a[s0:s0 + ln] |= 0x20
+        if kind.startswith("iupac") and kind not in ("iupac20",):
+            k = int(kind[5:])
+            a[rng.integers(0, L, k)] = rng.choice(np.frombuffer(b"RYKMSWN", dtype=np.uint8), k)
         out.append(a)
     return out
 ref = None
-for kind in ("pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac100"):
+KINDS = [k for k in sys.argv[4:] if not k.startswith("exc_limit=")] or ["pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac100"]
+OPTS = {k.split("=")[0]: int(k.split("=")[1]) for k in sys.argv[4:] if k.startswith("exc_limit=")}
+for kind in KINDS:
     seqs = variant(kind)
-    ctx = HipContext(0)
+    ctx = HipContext(0, **OPTS)
     ctx.upload(seqs)
     ctx.pairs(0, 2)
     best = 1e9
