@@ -255,9 +255,8 @@ __device__ __forceinline__ void snk_exc_match(SnkFastLane &L, uint32_t cur, uint
 }
 
 // the byte-accurate counterpart of snk_fast_finish
-__device__ __forceinline__ void snk_exc_finish(SnkFastLane &L, uint32_t cur, uint32_t cand, bool valid)
+__device__ __forceinline__ void snk_exc_finish(SnkFastLane &L, uint32_t cur, uint32_t cand, bool valid, uint64_t wc)
 {
-    const uint64_t wc = snk_ld8(L.g, cur);
     const uint64_t wd = snk_ld8(L.g, valid ? cand : cur);
     if (valid & ((uint32_t)wc == (uint32_t)wd)) {
         snk_exc_match(L, cur, cand);
@@ -411,13 +410,16 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
         snk_exc_seek(L, cur);
         // the positions put below may have an exception in their windows (by the granule flags: a superset): the steady
         // loop then compares with the mask window for as long as such an entry can be read (65 535 bytes)
-        if (!snk_exc_clean(L, cur) || (L.pending && !snk_exc_clean(L, cur - 2u))) { L.mask_until = cur + 65536u; SNK_COUNT(6); }
+        // (a cursor at L.xlim stands at a site -- the caller keeps xlim at the first position >= the cursor whose window is
+        // not clean -- and needs no look at the flags)
+        if (cur >= L.xlim || !snk_exc_clean(L, cur) || (L.pending && !snk_exc_clean(L, cur - 2u))) { L.mask_until = cur + 65536u; SNK_COUNT(6); }
         if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
-        const uint32_t h = snk_hash5(snk_ld8(L.g, cur));
+        const uint64_t wc = snk_ld8(L.g, cur);
+        const uint32_t h = snk_hash5(wc);
         bool valid;
         const uint32_t cand = snk_exc_get(L, T, tbl, bm, h, cur, valid);
         snk_exc_put(L, T, tbl, bm, h, cur);
-        snk_exc_finish(L, cur, cand, valid);
+        snk_exc_finish(L, cur, cand, valid, wc);
         return false;
     }
     const uint32_t wc = snk_fetch32(L.s, cur);
@@ -804,7 +806,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         uint32_t cand = (uint32_t)(T0 + (int32_t)t);
         if (valid && !snk_exc_clean(L, cand)) {                   // an exception near the candidate: the real bytes decide
             SNK_COUNT(2);
-            snk_exc_finish(L, cur, cand, valid);
+            snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
         } else {
             // Cursor and candidate windows are clean here, so the 2-bit windows -- hot in the L1 -- decide the
             // ordinary cases exactly as the loop would; a match that may run on beyond them (back-extension 4,
@@ -1063,7 +1065,7 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
             if (EXC && !flushing && waiting == 0u && have && L.cur + L.step <= L.mfl1 && L.cur >= L.xlim)
                 { waiting = 1u; SNK_COUNT(5); }              // at an exception site: wait for company
             bool ok = !have || parked || waiting != 0u || snk_fast_eligible<EXC>(L);
-            if (!ok && L.cur + L.step <= L.mfl1) {           // inside a block: can the reservoir be re-seated?
+            if (!ok && L.cur + L.step <= L.mfl1 && (!EXC || L.cur < L.xlim)) {   // inside a block (and not at an exception site): can the reservoir be re-seated?
                 const uint32_t cur = L.cur, lx = L.s.lx;
                 if (cur >= lx + 4u) {
                     if (L.w.org != lx && anyx) parked = true;                 // first time on y

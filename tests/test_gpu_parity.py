@@ -271,6 +271,20 @@ def test_sequences_with_a_few_exceptions_stay_on_the_2bit_kernel(hip, oracle_mod
         assert np.array_equal(ctx.pairs(), exp_p[:7, :7])
 
 
+def test_fast_chains_reports_the_workgroup_geometry(hip):
+    """snk_fast_chains: lanes x waves of a 2-bit kernel workgroup; fast_lanes = 0 (the default) takes as many chains as the
+    160 KiB of LDS hold beside the slot LUT: 84 at 4 waves, and explicit settings are reported as given or refused."""
+    with hip.HipContext(0) as ctx:
+        assert ctx.fast_chains() == 84
+    with hip.HipContext(0, fast_waves=3) as ctx:
+        assert ctx.fast_chains() == 84                   # 28 x 3
+    with hip.HipContext(0, fast_lanes=5, fast_waves=2) as ctx:
+        assert ctx.fast_chains() == 10
+    with hip.HipContext(0, fast_lanes=30, fast_waves=4) as ctx:
+        with pytest.raises(hip.HipBackendError):
+            ctx.fast_chains()
+
+
 def test_soft_masked_genomes_stay_on_the_2bit_kernel(hip, oracle_mod):
     """Lower-case stretches (soft-masked genomes) are runs of exceptions for the 2-bit kernel: up to a quarter of a
     sequence's 16-base granules may be flagged by default.  Sizes equal the oracle's; both loops; next to a pure genome."""
