@@ -77,6 +77,19 @@ def pmc_traffic(rows, n, length, codec="lz4"):
     return None, None
 
 
+def cycle_account():
+    """Where the waves of the 2-bit kernel spend their cycles (stats build, tools/gpu_account.py), from the committed summary:
+    the bound that limits the kernel is instruction issue and dependent latency inside its probe loop, not HBM."""
+    name = "r02_cycle_account.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            a = json.load(f)
+        return {"cycles_per_trip_in_loop": a["cycles_per_trip_in_loop"], "trips_per_loop_entry": a["trips_per_entry"],
+                "share_outside_loop_with_counters": a["share_outside_loop"], "source": f"profiles/{name} (diagnostic build, 256 x 1 Mbp)"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cgroup_cpu_quota():
     """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
     try:
@@ -466,6 +479,7 @@ def main():
                          "kernel_ms_region_torch_events": kern_ms_region,
                          "alg_bytes_per_launch": alg_bytes_launch},
             "latency_bound": latency_bound,
+            "cycle_account": cycle_account() if args.codec == "lz4" else None,
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": parity, "allgather_check": gather_ok,
             "setup_s": {"generate": round(t_gen, 2), "upload_and_singles": round(t_upload, 2)},
