@@ -402,10 +402,10 @@ template <bool EXC>
 __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                               const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
-    uint32_t cur = L.cur;
+    const uint32_t cur = L.cur;
     if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
         return snk_fast_block_step<EXC>(L, T, tbl, bm, slot, out, status);
-    if (EXC) for (uint32_t it = 0u;; ++it) {                 // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
+    if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
         SNK_COUNT(1);
         snk_exc_seek(L, cur);
         // the positions put below may have an exception in their windows (by the granule flags: a superset): the steady
@@ -420,17 +420,7 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
         const uint32_t cand = snk_exc_get(L, T, tbl, bm, h, cur, valid);
         snk_exc_put(L, T, tbl, bm, h, cur);
         snk_exc_finish(L, cur, cand, valid, wc);
-        // A lower-case stretch is hundreds of these in a row: go on here, without the caller's round trip through its
-        // eligibility tests, while the next cursor still stands at the run the seek points to (window [q-4, q+12) against
-        // the run [a, b): the seek has made sure that b + 4 > q, so it touches iff a < q + 12).  A general probe is right
-        // anywhere, so this is only about who does it; block ends and everything else stay with the caller.
-        cur = L.cur;
-        if (it >= 127u || L.endcode != 0u || cur + L.step > L.mfl1) return false;
-        snk_exc_seek(L, cur);
-        const uint32_t *r = L.ron_y ? L.ry : L.rx;
-        if (!r) return false;
-        const uint32_t a = r[2u * L.ri];
-        if (a == 0xFFFFFFFFu || a >= cur - (L.ron_y ? L.s.lx : 0u) + 12u) return false;
+        return false;
     }
     const uint32_t wc = snk_fetch32(L.s, cur);
     const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
