@@ -68,7 +68,8 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *   "bytes_compact" -1 auto (default) / 0 never: compact table of the byte kernel when the
  *                   resident sequences use <= 2048 distinct 5-byte hashes (set before upload)
  *   "bytes_legacy"  1 = linked-mode byte jobs use the legacy u32-table kernel (testing)
- *   "exc_limit"     a sequence with bytes other than ACGT (N runs, IUPAC codes, lower-case stretches) stays on the 2-bit
+ *   "exc_limit"     a sequence with bytes other than ACGT (acgt in a set that is mostly lower case) -- N runs, IUPAC codes,
+ *                   stretches in the other case -- stays on the 2-bit
  *                   kernel while at most 8 * exc_limit of its 16-base granules per 2^20 bases hold one and it has at most
  *                   4 + 1.25 * exc_limit such runs per 2^20 bases (default 2048: a quarter of the granules, 2564 runs per
  *                   Mbp); 0 = pure ACGT only.  Set before snk_upload.

@@ -62,6 +62,7 @@ struct snk_ctx_impl {
     std::vector<uint8_t> is_packed;  // goes to the 2-bit kernel: pure ACGT, or ACGT with a few exceptions
     std::vector<uint8_t> has_exc;    // ... the latter
     bool any_exc = false;
+    bool lower = false;              // the resident set's letters are acgt: its 2-bit sequences, LUTs and exceptions go by the lower case
     long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (a quarter of
                                      // them at 2048) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload)
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
@@ -129,19 +130,35 @@ uint32_t host_hash5(const uint8_t *p)
     return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
 }
 
-bool build_luts(std::vector<uint16_t> &slot, std::vector<uint32_t> &hash)
+// lower: the LUTs of a lower-case set (the 2-bit code (c >> 1) & 3 is the same for a letter's two cases; liblz4's hash
+// of the bytes is not: 894 slots for ACGT, 895 for acgt -- the last slot of the table stays free for "nothing owed")
+bool build_luts(std::vector<uint16_t> &slot, std::vector<uint32_t> &hash, bool lower = false)
 {
     slot.assign(1024, 0); hash.assign(1024, 0);
     std::vector<int> slot_of_hash(4096, -1);
     int n_slots = 0;
     for (uint32_t k = 0; k < 1024; ++k) {
         uint8_t b[5];
-        for (int i = 0; i < 5; ++i) b[i] = (uint8_t)kCodeToByte[(k >> (2 * i)) & 3];
+        for (int i = 0; i < 5; ++i) b[i] = (uint8_t)(kCodeToByte[(k >> (2 * i)) & 3] | (lower ? 0x20 : 0));
         hash[k] = host_hash5(b);
         if (slot_of_hash[hash[k]] < 0) slot_of_hash[hash[k]] = n_slots++;
         slot[k] = (uint16_t)slot_of_hash[hash[k]];
     }
-    return n_slots <= (int)SNK_FSLOTS;               // 894 for liblz4's hash5
+    return n_slots < (int)SNK_FSLOTS;
+}
+
+// The 2-bit kernel's LUTs for the context's letter case, to the device.
+int upload_luts(snk_ctx_impl *c)
+{
+    std::vector<uint16_t> slot; std::vector<uint32_t> hash;
+    if (!build_luts(slot, hash, c->lower)) return fail(c, SNK_E_STATE, "5-mer slot count exceeds the table");
+    std::vector<uint16_t> h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);       // hash <-> slot (general path of sequences with exceptions)
+    for (uint32_t k = 0; k < 1024; ++k) { h2s[hash[k]] = slot[k]; s2h[slot[k]] = (uint16_t)hash[k]; }
+    HIPCHK(c, hipMemcpy(c->d_lut_h2s, h2s.data(), 8192, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_lut_s2h, s2h.data(), SNK_FSLOTS * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_lut_slot, slot.data(), 2048, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_lut_hash, hash.data(), 4096, hipMemcpyHostToDevice));
+    return SNK_OK;
 }
 
 SnkTables make_tables(const snk_ctx_impl *c)
@@ -479,27 +496,14 @@ int snk_ctx_create(int device, snk_ctx **out)
     CRCHK(hipMalloc((void **)&c->d_zero, 4 * SNK_PAD));
     CRCHK(hipMemset(c->d_zero, 0, 4 * SNK_PAD));
     {
-        std::vector<uint16_t> slot; std::vector<uint32_t> hash;
-        if (!build_luts(slot, hash)) {
-            fail(nullptr, SNK_E_STATE, "5-mer slot count exceeds the table");
-            snk_ctx_destroy(c);
-            return SNK_E_STATE;
-        }
         CRCHK(hipMalloc((void **)&c->d_lut_h2c, 4096 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_h2c4, 8192 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_hashset, (128 + 256) * sizeof(uint32_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_slot, 1024 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_hash, 1024 * sizeof(uint32_t)));
-        {   // hash <-> slot of the 2-bit table (general path of sequences with exceptions)
-            std::vector<uint16_t> h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);
-            for (uint32_t k = 0; k < 1024; ++k) { h2s[hash[k]] = slot[k]; s2h[slot[k]] = (uint16_t)hash[k]; }
-            CRCHK(hipMalloc((void **)&c->d_lut_h2s, 4096 * sizeof(uint16_t)));
-            CRCHK(hipMalloc((void **)&c->d_lut_s2h, SNK_FSLOTS * sizeof(uint16_t)));
-            CRCHK(hipMemcpy(c->d_lut_h2s, h2s.data(), 8192, hipMemcpyHostToDevice));
-            CRCHK(hipMemcpy(c->d_lut_s2h, s2h.data(), SNK_FSLOTS * 2, hipMemcpyHostToDevice));
-        }
-        CRCHK(hipMemcpy(c->d_lut_slot, slot.data(), 2048, hipMemcpyHostToDevice));
-        CRCHK(hipMemcpy(c->d_lut_hash, hash.data(), 4096, hipMemcpyHostToDevice));
+        CRCHK(hipMalloc((void **)&c->d_lut_h2s, 4096 * sizeof(uint16_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_s2h, SNK_FSLOTS * sizeof(uint16_t)));
+        if (upload_luts(c) != SNK_OK) { snk_ctx_destroy(c); return SNK_E_STATE; }
     }
 #undef CRCHK
     *out = c;
@@ -636,6 +640,28 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
                     "(callers split the matrix into blocks of sequences: snacc_amd.cli.blocked_sizes)", btot,
                     (unsigned long long)c->arena_limit);
 
+    {   // The set's letter case, from a sample (up to 8 KiB from the middle of every sequence): the 2-bit kernel serves
+        // ONE case per upload -- its slots are liblz4's hashes of the bytes -- and the other case's letters are exceptions
+        // like any other byte (a soft-masked set goes by its majority).
+        uint64_t up = 0, lo = 0;
+        for (size_t g = 0; g < n; ++g) {
+            const uint64_t m = std::min<uint64_t>(lens[g], 8192), s0 = (lens[g] - m) / 2;
+            for (uint64_t i = s0; i < s0 + m; ++i) {
+                const uint8_t ch = seqs[g][i];
+                if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') up++;
+                else if (ch == 'a' || ch == 'c' || ch == 'g' || ch == 't') lo++;
+            }
+        }
+        const bool lower = lo > up;
+        if (lower != c->lower) {
+            c->lower = lower;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int rc = upload_luts(c);
+            if (rc != SNK_OK) return rc;
+        }
+    }
+    const uint32_t lcase = c->lower ? 0x20u : 0u;                 // ORed into 'A' 'C' 'G' 'T': the set's four letters
+
     HIPCHK(c, hipMalloc((void **)&c->d_bytes, btot));
     HIPCHK(c, hipMemsetAsync(c->d_bytes, 0, btot, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -658,7 +684,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         if (!lens[g]) continue;
         uint32_t grid = (uint32_t)std::min<uint64_t>(((lens[g] + 15) / 16 + 255) / 256, 1024);
         hipLaunchKernelGGL(snk_excraw_kernel, dim3(grid), dim3(256), 0, c->stream,
-                           c->d_bytes + boff[g], (uint64_t)lens[g], d_raw + foff[g], d_cnt + g);
+                           c->d_bytes + boff[g], (uint64_t)lens[g], d_raw + foff[g], d_cnt + g, lcase);
     }
     std::vector<uint32_t> ecount(n);
     HIPCHK(c, hipMemcpyAsync(ecount.data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -690,7 +716,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
                     bits &= bits - 1;
                     for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
                         const uint8_t ch = seqs[g][i];
-                        if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
+                        if (ch == ('A' | lcase) || ch == ('C' | lcase) || ch == ('G' | lcase) || ch == ('T' | lcase)) continue;
                         if (runs.size() > first && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;       // extends the open run
                         else { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); }
                     }
@@ -746,7 +772,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
             uint64_t nb = ((uint64_t)lens[g] + 3) / 4;
             uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 2048);
             hipLaunchKernelGGL(snk_packmask_kernel, dim3(grid), dim3(256), 0, c->stream,
-                               c->d_bytes + boff[g], (uint64_t)lens[g], c->d_pmask + poff[g]);
+                               c->d_bytes + boff[g], (uint64_t)lens[g], c->d_pmask + poff[g], lcase);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -774,7 +800,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (any_packed) {
                 std::vector<uint16_t> slot; std::vector<uint32_t> hash;
-                build_luts(slot, hash);
+                build_luts(slot, hash, c->lower);
                 for (uint32_t k = 0; k < 1024; ++k) set[hash[k] >> 5] |= 1u << (hash[k] & 31u);
             }
             std::vector<uint16_t> h2c(4096, 0xFFFF);

@@ -24,7 +24,8 @@ __global__ void snk_classify_kernel(const uint8_t *bytes, uint64_t n, uint32_t *
 
 // Exception granules (2-bit kernel on sequences with a few non-ACGT bytes, snk_fast.hip.h): one thread per
 // 16-base granule; raw[g] is set when the granule holds a byte outside {A,C,G,T}; *count += flagged granules.
-__global__ void snk_excraw_kernel(const uint8_t *bytes, uint64_t n, uint32_t *raw, uint32_t *count)
+// lcase: 0x20 for a lower-case set (its letters are acgt), else 0.
+__global__ void snk_excraw_kernel(const uint8_t *bytes, uint64_t n, uint32_t *raw, uint32_t *count, uint32_t lcase)
 {
     const uint64_t ngran = (n + 15u) >> 4;
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,7 +35,7 @@ __global__ void snk_excraw_kernel(const uint8_t *bytes, uint64_t n, uint32_t *ra
         bool bad = false;
         for (uint32_t b = 0; b < 16u; ++b) {
             const uint64_t i = g * 16u + b;
-            if (i < n) { const uint8_t c = bytes[i]; bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+            if (i < n) { const uint32_t c = bytes[i]; bad |= !(c == ('A' | lcase) || c == ('C' | lcase) || c == ('G' | lcase) || c == ('T' | lcase)); }
         }
         if (bad) { atomicOr(&raw[g >> 5], 1u << (g & 31u)); mine++; }
     }
@@ -71,7 +72,7 @@ __global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packe
 
 // The mask arena of the 2-bit kernel (sequences with exceptions): same layout as the packed bytes, 11 where the byte
 // is not one of ACGT, 00 elsewhere and behind the end.
-__global__ void snk_packmask_kernel(const uint8_t *bytes, uint64_t n, uint8_t *mask)
+__global__ void snk_packmask_kernel(const uint8_t *bytes, uint64_t n, uint8_t *mask, uint32_t lcase)
 {
     uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nbytes = (n + 3) >> 2;
@@ -80,7 +81,7 @@ __global__ void snk_packmask_kernel(const uint8_t *bytes, uint64_t n, uint8_t *m
         uint32_t v = 0;
         for (uint32_t b = 0; b < 4u; ++b) {
             const uint64_t i = o * 4 + b;
-            if (i < n) { const uint8_t c = bytes[i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) v |= 3u << (2u * b); }
+            if (i < n) { const uint32_t c = bytes[i]; if (!(c == ('A' | lcase) || c == ('C' | lcase) || c == ('G' | lcase) || c == ('T' | lcase))) v |= 3u << (2u * b); }
         }
         mask[o] = (uint8_t)v;
     }

@@ -313,6 +313,33 @@ def test_soft_masked_genomes_stay_on_the_2bit_kernel(hip, oracle_mod):
         assert np.array_equal(p, exp_p), (opts, np.argwhere(p != exp_p)[:8].tolist())
 
 
+def test_lower_case_sets_run_on_the_2bit_kernel(hip, oracle_mod):
+    """A set whose letters are acgt runs on the 2-bit kernel like an upper-case one (its LUTs are made from liblz4's
+    hashes of the lower-case 5-mers; upper-case stretches are then the exceptions); the case goes by the set's majority,
+    and a context that has served one case serves the other after the next upload."""
+    o = oracle_mod
+    rng = np.random.default_rng(31)
+    g = [o.lcg_genome(500 + k, n) for k, n in enumerate([200000, 131072, 90001, 262144, 70000])]
+    lower = [np.frombuffer(bytes(x).lower(), dtype=np.uint8).copy() for x in g]
+    lower[1][5000:5600] &= 0xDF                           # an upper-case stretch in a lower-case genome
+    lower[3][70000:70050] = ord("n")
+    lower[3][131000:131300] &= 0xDF
+    upper = [x.copy() for x in g[:3]]
+    with hip.HipContext(0, fast_lanes=4, fast_waves=2) as ctx:
+        for seqs in (lower, upper, lower[:2] + [g[4]]):   # (the last: two lower-case genomes and an upper-case one: majority lower)
+            exp_s = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
+            exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+            ctx.upload(seqs)
+            s, p = ctx.singles(), ctx.pairs()
+            assert np.array_equal(s, exp_s), np.flatnonzero(s != exp_s)
+            assert np.array_equal(p, exp_p), np.argwhere(p != exp_p)[:8].tolist()
+    with hip.HipContext(0) as ctx:
+        ctx.upload(lower)
+        assert ctx.num_packed == len(lower)               # all five on the 2-bit kernel
+        ctx.upload(lower[:2] + [g[4]])
+        assert ctx.num_packed == 2                        # the upper-case genome of a lower-case set takes the byte kernel
+
+
 def test_related_genomes_same_ancestor(hip, oracle_mod):
     o = oracle_mod
     anc = o.lcg_genome(40, 180000)

@@ -19,6 +19,8 @@ def variant(kind):
             s0 = int(rng.integers(0, L - 2000)); a[s0:s0 + 1000] = ord("N")
         if kind in ("iupac20", "n10x100+iupac20"):
             a[rng.integers(0, L, 20)] = rng.choice(np.frombuffer(b"RYKMSWN", dtype=np.uint8), 20)
+        if kind == "lower":                                # a lower-case set: the 2-bit kernel with the lower-case LUTs
+            a |= 0x20
         if kind.startswith("soft"):                        # soft-masked: PCT % lower case in runs of about 500 bases
             pct = int(kind[4:])
             for s0 in rng.integers(0, L - 600, max(1, L * pct // 100 // 500)):
