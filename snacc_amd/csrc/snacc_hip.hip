@@ -535,7 +535,7 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         if (value < 0 || value > 64) return fail(c, SNK_E_ARG, "fast_lanes must be 0 (as many as fit) or 1..64");
         c->fast_lanes = (int)value;
     } else if (k == "fast_waves") {
-        if (value < 1 || value > 16) return fail(c, SNK_E_ARG, "fast_waves must be 1..16");
+        if (value < 1 || value > 8) return fail(c, SNK_E_ARG, "fast_waves must be 1..8");
         c->fast_waves = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;

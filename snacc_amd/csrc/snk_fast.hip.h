@@ -1096,35 +1096,35 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 
 #ifndef SNK_HOST_EMU
 // phase B: ordered pairs (the dominant kernel of the bench)
-__global__ void snk_fast_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void __launch_bounds__(512) snk_fast_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
 }
 
 // the same with the C++ statement of the steady loop (option fast_asm = 0: cross-check of the
 // hand-scheduled loop in the tests, A/B timing)
-__global__ void snk_fast_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void __launch_bounds__(512) snk_fast_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<false, false>(T, G, lanes, out, status);
 }
 
 // phase A: single sequences + prefix snapshots at upload (same code, own symbol so that profiles
 // keep the two phases apart)
-__global__ void snk_fast_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void __launch_bounds__(512) snk_fast_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
 }
 
 // the three again for resident sets in which some 2-bit sequence has exceptions (N runs, IUPAC codes)
-__global__ void snk_fastx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void __launch_bounds__(512) snk_fastx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, true>(T, G, lanes, out, status);
 }
-__global__ void snk_fastx_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void __launch_bounds__(512) snk_fastx_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<false, true>(T, G, lanes, out, status);
 }
-__global__ void snk_fastx_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+__global__ void __launch_bounds__(512) snk_fastx_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, true>(T, G, lanes, out, status);
 }
