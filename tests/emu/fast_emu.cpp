@@ -15,16 +15,18 @@ uint32_t host_hash5(const uint8_t *p)
     return (uint32_t)(((v << 24) * 889523592379ull) >> 52);
 }
 
-bool acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+uint8_t g_lcase = 0;      // 0x20: the set's letters are acgt (as snk_upload decides by the majority)
+bool acgt(uint8_t c) { return c == ('A' | g_lcase) || c == ('C' | g_lcase) || c == ('G' | g_lcase) || c == ('T' | g_lcase); }
 
 } // namespace
 
 // exc_limit: flagged 16-base granules per 2^20 bases (+8) up to which a sequence with non-ACGT bytes stays on
 // the 2-bit kernel (0: pure ACGT only).  Entries of `singles` / `pairs` that the kernel does not serve stay 0.
 extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t *lens,
-                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit)
+                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit, uint32_t lower)
 {
-    const char code2byte[4] = { 'A', 'C', 'T', 'G' };
+    g_lcase = lower ? 0x20 : 0;
+    const char code2byte[4] = { (char)('A' | g_lcase), (char)('C' | g_lcase), (char)('T' | g_lcase), (char)('G' | g_lcase) };
     std::vector<uint16_t> slot(1024, 0), h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);
     {
         std::vector<int> slot_of_hash(4096, -1);
@@ -37,7 +39,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
             slot[k] = (uint16_t)slot_of_hash[h];
             h2s[h] = slot[k]; s2h[slot[k]] = (uint16_t)h;
         }
-        if (n_slots > (int)SNK_FSLOTS) return -1;
+        if (n_slots >= (int)SNK_FSLOTS) return -1;         // (the last slot stays free: "nothing owed" puts go there)
     }
     std::vector<uint8_t> ok((size_t)n, 0), exc((size_t)n, 0);
     std::vector<uint32_t> poff((size_t)n, 0), boff((size_t)n, 0), len((size_t)n), spos((size_t)n), eoff((size_t)n, 0xFFFFFFFFu);

@@ -166,3 +166,19 @@ def test_emu_soft_masked_stretches():
     seqs[0][65000:66100] |= 0x20                        # ... across a block edge
     assert all(_packable(x, 65536) for x in seqs)       # (all of them run in the emulated kernel)
     check(seqs, exc_limit=65536)
+
+
+def test_emu_lower_case_set():
+    """A set in lower case: the same kernel code with the LUTs of the lower-case 5-mers (895 slots: the table's last slot
+    stays free) and acgt as the alphabet; upper-case stretches and an n run are its exceptions."""
+    o = oracle
+    g = [o.lcg_genome(600 + k, n) for k, n in enumerate([150000, 131073, 90000, 200001])]
+    seqs = [np.frombuffer(bytes(x).lower(), dtype=np.uint8).copy() for x in g]
+    seqs[1][40000:40700] &= 0xDF                        # an upper-case stretch
+    seqs[3][70000:70060] = ord("n")
+    seqs[3][131000:131200] &= 0xDF
+    s, p = fast_sizes(seqs, exc_limit=65536, lower=True)
+    es = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    ep = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    assert np.array_equal(s, es), (s, es)
+    assert np.array_equal(p, ep), np.argwhere(p != ep)[:8].tolist()
