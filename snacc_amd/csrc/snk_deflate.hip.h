@@ -18,6 +18,9 @@ constexpr uint32_t DFL_HIST = 320u;            // 0..285 literal/length codes, 2
 constexpr uint32_t DFL_DOFF = 288u;
 constexpr uint32_t DFL_HEAP = 573u;            // 2 * L_CODES + 1
 constexpr uint32_t DFL_WAVES = 4u;             // wavefronts per workgroup
+#ifndef DFL_WIDE_K
+#define DFL_WIDE_K true                           // gzip kernel: the flush call's wide form (see dfl_flush)
+#endif
 #ifndef DFL_KW
 #define DFL_KW 16u                               // bucket members the K-pass looks at first (then 64 at a time)
 #endif
@@ -760,7 +763,8 @@ __device__ __attribute__((noinline)) DflBlockState dfl_flush_call(DflBlockState 
 // The same call with the whole struct passed and returned by value.  Either form keeps the hot loop free of the
 // per-symbol scratch traffic; which one the register allocator likes better differs between the two instantiations of
 // the parse body (measured, pair-compressions/s at 1024 x 1 Mbp: gzip kernel 151.6 k wide / 130.1 k slim, zlib
-// kernel 155.0 k wide / 167.2 k slim), so each uses its better one.
+// kernel 155.0 k wide / 167.2 k slim; again after the 16-byte index records: gzip 169.6 k wide / 141.0 k slim), so each uses
+// its better one (-DDFL_WIDE_K=false builds the gzip kernel with the slim form).
 __device__ __attribute__((noinline)) DflWave dfl_flush_call_wide(DflWave w, bool last, uint32_t p0, uint32_t end)
 {
     dfl_flush_body(w, last, p0, end);
@@ -1149,7 +1153,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
         DFL_T(tb); acc_search += tb - ta;
         if (prev_length >= 3u && match_length <= prev_length) {
             const uint32_t q = p - 1u;
-            dfl_emit<USE_K>(w, true, q, 0u, prev_length, q - prev_match);
+            dfl_emit<DFL_WIDE_K && USE_K>(w, true, q, 0u, prev_length, q - prev_match);
             p = q + prev_length;
             match_available = false;
             match_length = 2u;
@@ -1164,7 +1168,7 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                 if (lo < sy.nsym && lo > 0u && posy[lo] == want && (symy[lo - 1u] >> 31)) { sync_k = lo; break; }
             }
         } else if (match_available) {
-            dfl_emit<USE_K>(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u);
+            dfl_emit<DFL_WIDE_K && USE_K>(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u);
             p++;
         } else {
             match_available = true;
@@ -1191,16 +1195,16 @@ __device__ __forceinline__ void dfl_parse_body(const DflTables &T, const DflJob 
                 const uint32_t q = yoff + posy[k - 1u];
                 if (!(sl >> 31) && q + 1u == n) break;           // zlib's after-loop literal: see dfl_emit
                 __builtin_amdgcn_wave_barrier();
-                dfl_flush<USE_K>(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u);
+                dfl_flush<DFL_WIDE_K && USE_K>(w, false, q + 1u, (sl >> 31) ? q + ((sl >> 16) & 0x7fffu) + 3u : q + 1u);
             }
         }
         __builtin_amdgcn_wave_barrier();
     } else if (match_available && p >= n) {
-        dfl_emit<USE_K>(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
+        dfl_emit<DFL_WIDE_K && USE_K>(w, false, p - 1u, dfl_byte(S, p - 1u), 0u, 0u, true);
     }
     __builtin_amdgcn_wave_barrier();
     DFL_T(t2);
-    if (w.price) dfl_flush<USE_K>(w, true, n, n);
+    if (w.price) dfl_flush<DFL_WIDE_K && USE_K>(w, true, n, n);
     DFL_T(t3);
 #ifdef DFL_STAMP
     if (lane == 0 && jid < 64u) {
