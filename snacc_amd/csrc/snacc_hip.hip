@@ -63,8 +63,8 @@ struct snk_ctx_impl {
     std::vector<uint8_t> has_exc;    // ... the latter
     bool any_exc = false;
     bool lower = false;              // the resident set's letters are acgt: its 2-bit sequences, LUTs and exceptions go by the lower case
-    long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (a quarter of
-                                     // them at 2048) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload)
+    long exc_limit = 4915;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (60 % of
+                                     // them at 4915) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload)
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
     uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr;
@@ -696,8 +696,10 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     // the flagged granules.  Measured against pure ACGT (tools/gpu_exc.py, 1 Mbp genomes): 100 / 300 / 1000 / 3000
     // scattered IUPAC codes per Mbp 75 / 58 / 37 / 20 %; 1 / 5 / 20 % lower case in runs of ~500 bases (soft-masked) 60 /
     // 23 / 15 %.  The byte kernels such sequences would go to run at 29 % (compact table: ACGT + N only), 14 % (<= 2048
-    // distinct hashes) or 6 % (full table: several IUPAC codes, or soft-masked) of the 2-bit rate, so a sequence stays
-    // on the 2-bit kernel up to a quarter of its 16-base granules flagged and 4 + 2560 sites per 2^20 bases.
+    // distinct hashes) or 6 % (full table: several IUPAC codes, or soft-masked) of the 2-bit rate; at 40 / 60 % lower case
+    // (a third / 45 % of the bases after the stretches' overlap) the 2-bit kernel still runs at 11 / 9 %.  So a sequence
+    // stays on it up to 60 % of its 16-base granules flagged and 4 + 6144 sites per 2^20 bases; the case with fewer
+    // letters is the flagged one (see the sample above).
     c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false;
     std::vector<uint32_t> eoff(n, 0xFFFFFFFFu), runs, roff(n, 0);
     {
