@@ -113,8 +113,23 @@ struct SnkFastLane {
 #ifdef SNK_STATS
 __device__ unsigned long long snk_stats[32];
 #define SNK_COUNT(i) atomicAdd(&snk_stats[i], 1ull)
+// per-lane events of the general path (one atomic per probe and lane: they slow a run with many exception sites down
+// several times over; -DSNK_STATS=2 counts them, the plain stats build keeps the cycle account undistorted)
+#if SNK_STATS + 0 >= 2
+#define SNK_COUNT_HEAVY(i) SNK_COUNT(i)
 #else
+#define SNK_COUNT_HEAVY(i) do { } while (0)
+#endif
+// the cycle account is kept in registers and added to snk_stats once, when the wave ends (atomics on the way would
+// change what they measure): every lane carries the same numbers, lane 0 reports them
+struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top; unsigned int entries, rounds; };
+#define SNK_PROF_ARG , SnkProf &P
+#define SNK_PROF_PASS , P
+#else
+#define SNK_PROF_ARG
+#define SNK_PROF_PASS
 #define SNK_COUNT(i) do { } while (0)
+#define SNK_COUNT_HEAVY(i) do { } while (0)
 #endif
 
 // =========================================================================
@@ -204,7 +219,7 @@ __device__ __forceinline__ void snk_exc_put(SnkFastLane &L, const SnkTables &T, 
         tbl[s] = (uint16_t)(pos - L.base);                          // (<= 65 527: puts end 12 bytes before the block does)
         atomicOr(&bm[s >> 5], 1u << (s & 31u));
     } else {
-        SNK_COUNT(7);
+        SNK_COUNT_HEAVY(7);
         L.ovf[h] = pos;
     }
 }
@@ -227,7 +242,7 @@ __device__ __forceinline__ uint32_t snk_exc_get(const SnkFastLane &L, const SnkT
 // liblz4's match accounting on the real bytes (cf. snk_fast_match_slow, which does it on 2-bit windows)
 __device__ __forceinline__ void snk_exc_match(SnkFastLane &L, uint32_t cur, uint32_t cand)
 {
-    SNK_COUNT(4);
+    SNK_COUNT_HEAVY(4);
     const SnkGenSrc &g = L.g;
     uint32_t ip = cur;
     while (ip > L.anchor && cand > 0u && snk_byte_at(g, ip - 1u) == snk_byte_at(g, cand - 1u)) { ip--; cand--; }
@@ -406,13 +421,13 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
         return snk_fast_block_step<EXC>(L, T, tbl, bm, slot, out, status);
     if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
-        SNK_COUNT(1);
+        SNK_COUNT_HEAVY(1);
         snk_exc_seek(L, cur);
         // the positions put below may have an exception in their windows (by the granule flags: a superset): the steady
         // loop then compares with the mask window for as long as such an entry can be read (65 535 bytes)
         // (a cursor at L.xlim stands at a site -- the caller keeps xlim at the first position >= the cursor whose window is
         // not clean -- and needs no look at the flags)
-        if (cur >= L.xlim || !snk_exc_clean(L, cur) || (L.pending && !snk_exc_clean(L, cur - 2u))) { L.mask_until = cur + 65536u; SNK_COUNT(6); }
+        if (cur >= L.xlim || !snk_exc_clean(L, cur) || (L.pending && !snk_exc_clean(L, cur - 2u))) { L.mask_until = cur + 65536u; SNK_COUNT_HEAVY(6); }
         if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
         const uint64_t wc = snk_ld8(L.g, cur);
         const uint32_t h = snk_hash5(wc);
@@ -648,12 +663,13 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
 template <bool ASM, bool EXC>
 __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, snk_g8 *const marena, uint16_t *tbl, uint32_t *bm,
-                                                const uint16_t *slot, uint32_t lds_off, uint32_t round_bases)
+                                                const uint16_t *slot, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
 {
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
 #ifdef SNK_STATS
     const unsigned long long stat_te = clock64();
     const bool stat_first = (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+    (void)stat_first;
 #endif
 #ifdef SNK_HOST_EMU
     const uint16_t *const lut0 = slot;
@@ -693,7 +709,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     uint32_t t; bool valid;
 #ifdef SNK_STATS
     const unsigned long long stat_t0 = clock64();
-    if (stat_first) atomicAdd(&snk_stats[27], stat_t0 - stat_te);
+    P.prologue += stat_t0 - stat_te;
 #endif
 #ifndef SNK_HOST_EMU
     if (ASM) {
@@ -793,10 +809,10 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         r0 = lo; r1 = hi; rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
         c = ncur; wc = nwc; s1 = ns1; s2 = m ? ns2 : (SNK_FSLOTS - 1u);
     }
-    SNK_COUNT(0);
+    SNK_COUNT_HEAVY(0);
 #ifdef SNK_STATS
     const unsigned long long stat_t1 = clock64();
-    if (stat_first) { atomicAdd(&snk_stats[13], stat_t1 - stat_t0); atomicAdd(&snk_stats[14], 1ull); }
+    P.loop += stat_t1 - stat_t0; P.entries++;
 #endif
     // hand every lane over in the state "table operations of the probe at c done, match not evaluated"
     L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
@@ -805,7 +821,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         const uint32_t cur = vb + c;
         uint32_t cand = (uint32_t)(T0 + (int32_t)t);
         if (valid && !snk_exc_clean(L, cand)) {                   // an exception near the candidate: the real bytes decide
-            SNK_COUNT(2);
+            SNK_COUNT_HEAVY(2);
             snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
         } else {
             // Cursor and candidate windows are clean here, so the 2-bit windows -- hot in the L1 -- decide the
@@ -837,7 +853,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     }
 #ifdef SNK_STATS
-    if (stat_first) atomicAdd(&snk_stats[24], clock64() - stat_t1);
+    P.finish += clock64() - stat_t1;
 #endif
 }
 
@@ -914,6 +930,8 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 
 #ifdef SNK_STATS
     const unsigned long long stat_w0 = clock64();
+    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u };        // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
+                                                                 //  nearly always inside -- good enough for an account)
 #endif
     const bool lane_on = lane < lanes;
     const uint32_t mine_off = SNK_FLUT_B + (wave * lanes + (lane_on ? lane : 0u)) * SNK_FCHAIN_B;   // LDS address: dynamic LDS starts at 0
@@ -935,6 +953,9 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     L.s.lx = 0u; L.s.yoff = 0u; L.cur = 0u;
 
     for (;;) {
+#ifdef SNK_STATS
+        const unsigned long long stat_o0 = clock64();
+#endif
         // ---- hand jobs to the lanes that have none ----
         bool need = lane_on && !have;
         while (!dry && __any(need)) {
@@ -1010,7 +1031,12 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         }
         if (!__any(have)) {
 #ifdef SNK_STATS
-            if (lane == 0u) atomicAdd(&snk_stats[7], clock64() - stat_w0);
+            if (lane == 0u) {
+                atomicAdd(&snk_stats[7], clock64() - stat_w0);
+                atomicAdd(&snk_stats[13], P.loop); atomicAdd(&snk_stats[14], (unsigned long long)P.entries);
+                atomicAdd(&snk_stats[24], P.finish); atomicAdd(&snk_stats[25], P.rounds_cyc); atomicAdd(&snk_stats[26], (unsigned long long)P.rounds);
+                atomicAdd(&snk_stats[27], P.prologue); atomicAdd(&snk_stats[28], P.probe); atomicAdd(&snk_stats[29], P.top);
+            }
 #endif
             return;
         }
@@ -1050,10 +1076,11 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         bool refill = false;                     // wave-uniform: a lane has finished and a job may be left for it
 #ifdef SNK_STATS
         const unsigned long long stat_i0 = clock64();
+        P.top += stat_i0 - stat_o0;                      // job hand-out, gathering at sites
 #endif
         for (;;) {
 #ifdef SNK_STATS
-            if (lane == 0u) SNK_COUNT(26);
+            P.rounds++;
 #endif
             // Lanes of a wave share their suffix y (jobs are suffix-major) but reach it after x tails of
             // different lengths.  A lane that arrives parks until no lane of the wave is inside its x any
@@ -1063,7 +1090,7 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
             if (EXC && have && L.cur >= L.xlim && L.cur + L.step <= L.mfl1)
                 L.xlim = snk_exc_next(L, L.cur);             // (the cursor itself when its window is not clean)
             if (EXC && !flushing && waiting == 0u && have && L.cur + L.step <= L.mfl1 && L.cur >= L.xlim)
-                { waiting = 1u; SNK_COUNT(5); }              // at an exception site: wait for company
+                { waiting = 1u; SNK_COUNT_HEAVY(5); }              // at an exception site: wait for company
             bool ok = !have || parked || waiting != 0u || snk_fast_eligible<EXC>(L);
             if (!ok && L.cur + L.step <= L.mfl1 && (!EXC || L.cur < L.xlim)) {   // inside a block (and not at an exception site): can the reservoir be re-seated?
                 const uint32_t cur = L.cur, lx = L.s.lx;
@@ -1079,18 +1106,18 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 #endif
             if (!ok && snk_fast_iter<EXC>(L, T, tbl, bm, slot, out, status)) have = false;   // frame complete
 #ifdef SNK_STATS
-            if (lane == 0u) atomicAdd(&snk_stats[28], clock64() - stat_g0);                 // inside the general probes
+            P.probe += clock64() - stat_g0;                                                 // inside the general probes
 #endif
             if (!dry && __any(lane_on && !have)) { refill = true; break; }
         }
 #ifdef SNK_STATS
-        if (lane == 0u) atomicAdd(&snk_stats[25], clock64() - stat_i0);
+        P.rounds_cyc += clock64() - stat_i0;
 #endif
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
         if (have && !parked && waiting == 0u)
             snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm, slot, mine_off,
-                                      0xFFFFFFFFu);
+                                      0xFFFFFFFFu SNK_PROF_PASS);
     }
 }
 

@@ -57,6 +57,6 @@ for kind in KINDS:
         if st[14]:
             print(f"   wave cycles {int(st[7]):,}: in the loop {st[13] / st[7]:.1%}, loop entries {int(st[14]):,}, per entry: outside {(st[7] - st[13]) / st[14]:,.0f} cycles"
                   f" (finish {st[24] / st[14]:,.0f}, general rounds {st[25] / st[14]:,.0f} in {st[26] / st[14]:.2f} rounds)"
-                  f"; per round {st[25] / max(1, st[26]):,.0f} cycles, of which inside the probe {st[28] / max(1, st[26]):,.0f}")
+                  f"; per round {st[25] / max(1, st[26]):,.0f} cycles, of which inside the probe {st[28] / max(1, st[26]):,.0f}; loop prologue {st[27] / st[14]:,.0f}, top of the outer loop {st[29] / st[14]:,.0f}")
     print(f"{kind:18s} packed={ctx.num_packed}/{N} ms={best:.1f} pairs/s={rate:.0f} ({rate / ref * 100:.0f}% of pure) parity={ok}", flush=True)
     ctx.close()
