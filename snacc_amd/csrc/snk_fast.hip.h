@@ -102,6 +102,8 @@ struct SnkFastLane {
     bool ron_y;                            // ... which sequence that is
     uint32_t *ovf;                         // this chain's overflow table
     uint32_t xlim;                         // first position >= the last scan whose window is not clean
+    uint32_t site_lo, site_hi;             // stream positions p in [site_lo, site_hi) are known to be unclean (the run the last
+                                           // scan found the cursor at): no look at the run list for them
     uint32_t mask_until;                   // cursors below this may read a table entry whose window holds an exception: the
                                            // steady loop then runs with the mask window (see "Exceptions" below)
 };
@@ -196,12 +198,14 @@ __device__ __forceinline__ bool snk_exc_clean_near(const SnkFastLane &L, uint32_
 __device__ __forceinline__ uint32_t snk_exc_next(SnkFastLane &L, uint32_t p)
 {
     const uint32_t lx = L.s.lx;
+    if (p - L.site_lo < L.site_hi - L.site_lo) return p;         // still at the run found last time
     snk_exc_seek(L, p);
     if (p + 12u <= lx) {
         const uint32_t stop = lx - 11u;                         // the seam gap at the latest
         if (!L.rx) return stop;
         const uint32_t a = L.rx[2u * L.ri];                      // first run that does not end before the window
         if (a == 0xFFFFFFFFu) return stop;
+        if (a < p + 12u) { L.site_lo = a > 11u ? a - 11u : 0u; L.site_hi = L.rx[2u * L.ri + 1u] + 4u; }
         const uint32_t q = a < p + 12u ? p : a - 11u;            // touching now, or from a - 11 on
         return q < stop ? q : stop;
     }
@@ -209,6 +213,7 @@ __device__ __forceinline__ uint32_t snk_exc_next(SnkFastLane &L, uint32_t p)
     if (!L.ry) return 0xFFFFFFFFu;
     const uint32_t a = L.ry[2u * L.ri];
     if (a == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+    if (a < (p - lx) + 12u) { L.site_lo = lx + (a > 11u ? a - 11u : 0u); L.site_hi = lx + L.ry[2u * L.ri + 1u] + 4u; }
     return a < (p - lx) + 12u ? p : lx + a - 11u;
 }
 
@@ -1021,7 +1026,7 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                     L.rx = L.fx ? T.exc_runs + 2u * T.exc_roff[job.xi] : nullptr;
                     L.ry = L.fy ? T.exc_runs + 2u * T.exc_roff[job.yi] : nullptr;
                     L.ri = 0u; L.ron_y = false;
-                    L.xlim = 0u;
+                    L.xlim = 0u; L.site_lo = L.site_hi = 0u;
                     // the start state (position 0 in every slot, or x's prefix snapshot) may point at exceptions of x
                     L.mask_until = L.fx ? L.pos + 65536u : 0u;
                 }
@@ -1055,14 +1060,12 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         if (EXC) {
             const unsigned long long wm = __builtin_amdgcn_ballot_w64(waiting != 0u);
             if (wm && !flushing) {
-                uint32_t wfront = 0u, wy = 0u;                   // wave-uniform: y position and suffix of the foremost waiting lane
-                bool in_x = false;
-                for (unsigned long long m = wm; m; m &= m - 1ull) {
-                    const int l = (int)__builtin_ctzll(m);
-                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)L.cur, l), xl = (uint32_t)__builtin_amdgcn_readlane((int)L.s.lx, l);
-                    if (cl < xl) in_x = true;
-                    else if (cl - xl >= wfront) { wfront = cl - xl; wy = (uint32_t)__builtin_amdgcn_readlane((int)L.s.yoff, l); }
-                }
+                // (the waiting lanes stand at one site as a rule: the first of them is the reference; a lane waiting elsewhere
+                // only makes the wait a little shorter or longer)
+                const int l0 = (int)__builtin_ctzll(wm);
+                const uint32_t wfront = (uint32_t)__builtin_amdgcn_readlane((int)(L.cur - L.s.lx), l0);
+                const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)L.s.yoff, l0);
+                const bool in_x = __any(waiting != 0u && L.cur < L.s.lx);
                 const bool runner = have && !parked && waiting == 0u && L.cur >= L.s.lx && L.s.yoff == wy;
                 const uint32_t ry = L.cur - L.s.lx;
                 const bool soon = runner && ry < wfront && wfront - ry < SNK_EXC_GATHER;
