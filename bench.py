@@ -85,7 +85,8 @@ def cycle_account():
         with open(os.path.join(ROOT, "profiles", name)) as f:
             a = json.load(f)
         return {"cycles_per_trip_in_loop": a["cycles_per_trip_in_loop"], "trips_per_loop_entry": a["trips_per_entry"],
-                "share_outside_loop_with_counters": a["share_outside_loop"], "source": f"profiles/{name} (diagnostic build, 256 x 1 Mbp)"}
+                "share_outside_loop": a["share_outside_loop"], "cycles_per_exit_outside_loop": a["cycles_per_exit_outside_loop"],
+                "source": f"profiles/{name} (diagnostic build with the account kept in registers, 256 x 1 Mbp)"}
     except (OSError, KeyError, ValueError):
         return None
 
