@@ -803,3 +803,31 @@ def test_rccl_single_rank_smoke(hip, oracle_mod, tmp_path):
     code = code.replace(repr(str(tmp_path.parent.parent)), repr(root))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
     assert res.returncode == 0 and "rccl-ok" in res.stdout, (res.stdout[-2000:], res.stderr[-3000:])
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """`python bench.py` prints ONE JSON line with the keys the driver and the judge read (metric, value, unit, n_gpus, steps,
+    warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload, roofline, cpu_baseline); a
+    small run of it, as a child process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--genomes", "128", "--steps", "2", "--warmup", "1",
+                          "--no-matrix", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "u8" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["parity_spot_check"] is True
