@@ -211,3 +211,20 @@ def test_single_item_gzip_needs_the_hip_backend_by_default(sample_fa, monkeypatc
     from snacc_amd.hip_backend import HipBackendError
     with pytest.raises(HipBackendError):
         compressed_size(sample_fa, "gzip")
+
+
+def test_bench_reads_the_committed_profile_summaries():
+    """bench.py quotes HBM traffic and the wave cycle account from the round's committed rocprofv3 / stats summaries
+    (profiles/r02_*.json): the files parse, name their source, and match the launch shape the bench line is quoted on."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for codec in ("lz4", "gzip", "zlib"):
+        traffic, src = bench.pmc_traffic(84, 1024, 1000000, codec)
+        assert traffic and traffic > 0 and src.startswith("profiles/r02_pmc_traffic"), (codec, traffic, src)
+    assert bench.pmc_traffic(84, 1000, 1000000)[0] is None           # another launch shape: no figure
+    acc = bench.cycle_account()
+    assert 300 < acc["cycles_per_trip_in_loop"] < 800 and 0 < acc["share_outside_loop"] < 0.5 and "profiles/" in acc["source"]
