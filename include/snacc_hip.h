@@ -21,6 +21,13 @@
  *  - the caller owns every host buffer; the library never keeps a host pointer
  *    after a call returns.  The library owns its device memory.
  *  - one snk_ctx is used from one thread at a time; contexts are independent.
+ *  - streams: snk_pairs_device calls on different streams of one context overlap when every resident
+ *    sequence is pure ACGT (dense tiles share nothing).  When a resident 2-bit sequence has exceptions
+ *    (N runs, IUPAC codes, stretches in the other case) every 2-bit launch uses the context's ONE set of
+ *    per-chain overflow tables (16 KiB per resident chain: 344 MB on a 256-CU device, allocated at the
+ *    first such launch): such launches wait for each other on the device, whatever their streams.
+ *    Launches that need a job list (mixed tiles, pair lists) share one list buffer per context and
+ *    wait, on the host, for the previous launch that read it.
  *  - there is NO CPU fallback: without a HIP device every entry point that
  *    computes fails with SNK_E_HIP.
  */
@@ -118,7 +125,9 @@ int snk_pairs(snk_ctx *ctx, int row_begin, int row_end, uint32_t *sizes /* host 
  * NULL = the context's own stream) and writes u32 sizes to DEVICE memory
  * `d_sizes` ((row_end-row_begin)*n_seq elements), e.g. a torch tensor that is
  * then all-gathered over RCCL.  Does not synchronise.  The device-side status
- * word is checked by the next blocking call or by snk_sync(). */
+ * word is checked by the next blocking call or by snk_sync().  One call covers at most
+ * 2^32 - 1 ordered pairs ((row_end-row_begin)*n_seq; SNK_E_TOOBIG beyond: tile the rows, as
+ * snk_pairs does). */
 int snk_pairs_device(snk_ctx *ctx, int row_begin, int row_end, void *d_sizes, void *hip_stream);
 
 /* Arbitrary ordered pairs: sizes[t] = len(compress(seq[ij[2t]] + seq[ij[2t+1]])).
@@ -129,8 +138,9 @@ int snk_pairs_list(snk_ctx *ctx, int n_pairs, const int32_t *ij, uint32_t *sizes
  * with -s/--save-compression).  Item t is the single sequence ij[2t] when ij[2t+1] == -1, else
  * the concatenation seq[ij[2t]] + seq[ij[2t+1]].  `offsets` has n_items+1 entries, offsets[t+1] -
  * offsets[t] = the frame size obtained from snk_singles / snk_pairs_list; frame t is written to
- * out[offsets[t] ...].  Bytes equal liblz4 1.9.3 LZ4F_compressFrame(prefs = NULL).  Not available
- * with the content_size option. */
+ * out[offsets[t] ...].  Bytes equal liblz4 1.9.3 LZ4F_compressFrame(prefs = NULL) or, with the
+ * content_size option, LZ4F_compressFrame with frameInfo.contentSize set (tests/golden/frame_hashes.json
+ * pins both). */
 int snk_frames_list(snk_ctx *ctx, int n_items, const int32_t *ij, const uint64_t *offsets, uint8_t *out);
 
 /* Wait for outstanding work on the context's stream / the given stream and
@@ -145,7 +155,9 @@ double snk_last_pairs_ms(snk_ctx *ctx);
 /* Device times (ms) of every snk_pairs_device / snk_pairs_list launch since the previous call
  * of this function, oldest first: up to `cap` values into ms[], returns how many launches were
  * logged (bench.py averages them over its timed steps), or a negative error code -- SNK_E_STATE
- * when a logged launch has not completed yet (call snk_sync first).  Clears the log. */
+ * when a logged launch has not completed yet (call snk_sync first).  Clears the log.  The log is kept
+ * from the first call of this function on (a context whose caller never reads it holds one event pair,
+ * not one per launch); that first call reports the most recent launch, if any. */
 int snk_pairs_ms_log(snk_ctx *ctx, double *ms, int cap);
 
 /* ---- FASTA ingest on the host ------------------------------------------

@@ -109,16 +109,27 @@ def lz4_matrix(files, reverse_complement, show_progress, save_directory=None):
     return gpu_matrix(files, "lz4", reverse_complement, show_progress, save_directory)
 
 
-def blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress=False):
+def _arena_limit():
+    return int(os.environ.get("SNACC_ARENA_LIMIT", str(0xFFF00000)))
+
+
+def blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress=False, world=1, rank=0, all_reduce=None):
     """Singles and all ordered pair sizes of a file set whose residues do not fit one upload (the device
     arenas are addressed with 32-bit offsets: about 4.29 GB of residues, e.g. 1000 bacterial genomes of
-    5 Mbp).  The files are cut into groups of at most half the limit; every pair of groups is uploaded
-    once and its ordered pairs (both directions) are computed from a pair list.  Same sizes as one
-    upload would give (each pair is a function of its two sequences only); G(G+1)/2 uploads for G groups."""
-    from .hip_backend import DEFLATE
+    5 Mbp).  The files are cut into groups of at most 45 % of the limit (by file size, an upper bound of
+    the residues); every pair of groups is uploaded once and its ordered pairs (both directions) are
+    computed from a pair list.  Same sizes as one upload would give (each pair is a function of its two
+    sequences only); G(G+1)/2 uploads for G groups.  An upload that still does not fit (arena padding
+    under a small limit) is split in halves; a single pair that does not fit cannot be computed at all
+    (an lz4 frame of more than 2.1 GB) and ends the run with a message.
+
+    Multi-rank (`world` > 1): the group pairs are dealt round-robin over the ranks -- no data-path
+    collective -- and the two result arrays are summed over the ranks at the end (`all_reduce(array)`:
+    every entry is written by exactly one rank, the others hold 0)."""
+    from .hip_backend import DEFLATE, ArenaTooBig
     n = len(files)
     sizes = [os.path.getsize(f) + 192 for f in files]            # >= residues + arena padding
-    cap = int(os.environ.get("SNACC_ARENA_LIMIT", str(0xFFF00000))) * 45 // 100
+    cap = _arena_limit() * 45 // 100
     groups, cur, tot = [], [], 0
     for i in range(n):
         if cur and tot + sizes[i] > cap:
@@ -131,24 +142,65 @@ def blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress=False
     deflate = algorithm in DEFLATE
     singles = np.zeros(n, dtype=np.int64)
     pairs = np.zeros((n, n), dtype=np.int64)
-    todo = [(a, b) for a in range(len(groups)) for b in range(a, len(groups))]
-    if show_progress:
-        todo = tqdm(todo)
-    for a, b in todo:
-        members = groups[a] + (groups[b] if b != a else [])
-        ctx.upload_fasta([files[i].absolute() for i in members], reverse_complement=reverse_complement)
-        na = len(groups[a])
-        if b == a:
+
+    def block(ga, gb):
+        """Ordered pairs between the files `ga` and `gb` (both directions), or inside `ga` when gb is None
+        (then the singles of `ga` too)."""
+        members = ga + (gb or [])
+        try:
+            ctx.upload_fasta([files[i].absolute() for i in members], reverse_complement=reverse_complement)
+        except ArenaTooBig as e:
+            big = ga if gb is None or len(ga) >= len(gb) else gb
+            if len(big) < 2:
+                raise click.ClickException(
+                    "the sequences of " + " and ".join(str(files[i]) for i in members) + " do not fit one upload "
+                    f"({e}); a pair of this size cannot be compressed on the device") from e
+            h1, h2 = big[:len(big) // 2], big[len(big) // 2:]
+            if gb is None:
+                block(h1, None), block(h2, None), block(h1, h2)
+            elif big is ga:
+                block(h1, gb), block(h2, gb)
+            else:
+                block(ga, h1), block(ga, h2)
+            return
+        na = len(ga)
+        if gb is None:
             s = ctx.deflate_singles(algorithm) if deflate else ctx.singles()
-            singles[groups[a]] = s.astype(np.int64)
+            singles[ga] = s.astype(np.int64) + GETSIZEOF_OVERHEAD
             ij = [(i, j) for i in range(na) for j in range(na)]
         else:
-            ij = [(i, na + j) for i in range(na) for j in range(len(groups[b]))]
+            ij = [(i, na + j) for i in range(na) for j in range(len(gb))]
             ij += [(j, i) for i, j in ij]
         got = (ctx.deflate_pairs_list(algorithm, ij) if deflate else ctx.pairs_list(ij)).astype(np.int64)
         for (i, j), v in zip(ij, got):
-            pairs[members[i], members[j]] = v
-    return singles + GETSIZEOF_OVERHEAD, pairs + GETSIZEOF_OVERHEAD
+            pairs[members[i], members[j]] = v + GETSIZEOF_OVERHEAD
+
+    todo = [(a, b) for a in range(len(groups)) for b in range(a, len(groups))][rank::max(world, 1)]
+    if show_progress and rank == 0:
+        todo = tqdm(todo)
+    for a, b in todo:
+        block(groups[a], groups[b] if b != a else None)
+    if world > 1:
+        singles, pairs = all_reduce(singles), all_reduce(pairs)
+    return singles, pairs
+
+
+def _sum_over_ranks(backend, device):
+    """all_reduce(SUM) of an int64 numpy array over the ranks (device tensors for RCCL, CPU tensors for gloo)."""
+    import torch
+    import torch.distributed as dist
+    from .distributed import _die
+
+    def reduce(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if backend == "nccl":
+            t = t.to(device)
+        try:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        except Exception as e:      # noqa: BLE001
+            _die("all_reduce", e)
+        return t.cpu().numpy()
+    return reduce
 
 
 def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directory=None, ctx_factory=None,
@@ -188,17 +240,25 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
         # every file is parsed ONCE, by host threads inside the library, then
         # uploaded; phase A (singles + prefix snapshots) runs as part of the upload
         from .hip_backend import ArenaTooBig
+        too_big = sum(os.path.getsize(f) for f in files) * 9 // 10 > _arena_limit()    # no point in parsing the whole set first
         try:
-            ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
+            if not too_big:
+                ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
         except ArenaTooBig:
-            if world > 1:
-                raise
+            too_big = True
+        if too_big:
+            if save_directory is not None:
+                raise click.ClickException("-s/--save-compression on the HIP backend needs the whole set in one upload "
+                                           "(the set exceeds the 4.29 GB of residues one upload holds)")
             if chatty:
                 click.secho("Compressing pairs...", fg="green")
-            singles, pairs = blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress)
-            if save_directory is not None:
-                raise click.ClickException("-s with lz4 needs the whole set in one upload (set too large)")
-            return ncd_matrix(singles, pairs)
+            reduce = None
+            if world > 1:
+                import torch
+                reduce = _sum_over_ranks(backend, torch.device("cuda", local) if backend == "nccl" else None)
+            singles, pairs = blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress and chatty,
+                                           world=world, rank=rank, all_reduce=reduce)
+            return ncd_matrix(singles, pairs) if rank == 0 else None
         deflate = algorithm in DEFLATE
         singles = (ctx.deflate_singles(algorithm) if deflate else ctx.singles()).astype(np.int64) + GETSIZEOF_OVERHEAD
         if chatty:

@@ -26,6 +26,7 @@ struct snk_ctx_impl {
     double ms_accum = -1.0;          // sum over the tiles of the last snk_pairs call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_log;   // one pair per pair launch since the last snk_pairs_ms_log
     size_t ev_used = 0;
+    bool ev_logging = false;         // a caller reads the log (snk_pairs_ms_log): keep one event pair per launch; else ONE pair, reused
     int n_cus = 0;                   // compute units of the device: size of a persistent launch
     uint32_t *d_yorder = nullptr;    // sequence indices by decreasing length (column order of ragged dense tiles)
     uint32_t *d_queue = nullptr;     // ring of batch counters for launches with the dynamic schedule
@@ -106,6 +107,13 @@ int fail(snk_ctx_impl *c, int code, const char *fmt, ...)
     } while (0)
 
 template <typename T> void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
+
+// device temporaries of one call: freed on every return path
+template <typename T> struct DevTemp {
+    T *p = nullptr;
+    ~DevTemp() { if (p) (void)hipFree((void *)p); }
+    void release() { if (p) { (void)hipFree((void *)p); p = nullptr; } }
+};
 
 void free_sequences(snk_ctx_impl *c)
 {
@@ -406,6 +414,7 @@ int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_bytes, si
         if (c->jobs_in_flight) { HIPCHK(c, hipEventSynchronize(c->jobs_busy)); c->jobs_in_flight = false; }
         HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), nj * sizeof(SnkJob), hipMemcpyHostToDevice, st));
     }
+    if (!c->ev_logging) c->ev_used = 0;          // nobody reads the log: slot 0 serves every launch (snk_last_pairs_ms)
     if (c->ev_used == c->ev_log.size()) {
         if (c->ev_log.size() < 4096) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -612,9 +621,21 @@ int snk_lengths(const snk_ctx *c, uint64_t *lens)
 }
 int snk_num_compact_hashes(const snk_ctx *c) { return c ? (c->compact_ok ? c->n_hashes : 0) : SNK_E_ARG; }
 
+static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens);
+
 int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens)
 {
     if (!c || n_seq < 0 || (n_seq > 0 && (!seqs || !lens))) return fail(c, SNK_E_ARG, "bad arguments");
+    const int rc = upload_impl(c, n_seq, seqs, lens);
+    if (rc != SNK_OK) {                      // a failed upload leaves no sequences resident and no device memory behind
+        (void)hipStreamSynchronize(c->stream);
+        free_sequences(c);
+    }
+    return rc;
+}
+
+static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens)
+{
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->jobs_in_flight) { HIPCHK(c, hipEventSynchronize(c->jobs_busy)); c->jobs_in_flight = false; }
@@ -675,9 +696,10 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     std::vector<uint32_t> foff(n, 0), fwords(n, 0);
     size_t ftot = 0;
     for (size_t g = 0; g < n; ++g) { fwords[g] = (uint32_t)((((size_t)lens[g] + 15) / 16 + 31) / 32 + 2); foff[g] = (uint32_t)ftot; ftot += fwords[g]; }
-    uint32_t *d_raw = nullptr, *d_cnt = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_raw, std::max<size_t>(ftot, 1) * 4));
-    HIPCHK(c, hipMalloc((void **)&d_cnt, n * sizeof(uint32_t)));
+    DevTemp<uint32_t> t_raw, t_cnt;
+    HIPCHK(c, hipMalloc((void **)&t_raw.p, std::max<size_t>(ftot, 1) * 4));
+    HIPCHK(c, hipMalloc((void **)&t_cnt.p, n * sizeof(uint32_t)));
+    uint32_t *const d_raw = t_raw.p, *const d_cnt = t_cnt.p;
     HIPCHK(c, hipMemsetAsync(d_raw, 0, std::max<size_t>(ftot, 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), c->stream));
     for (size_t g = 0; g < n; ++g) {
@@ -689,7 +711,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     std::vector<uint32_t> ecount(n);
     HIPCHK(c, hipMemcpyAsync(ecount.data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    dfree(d_cnt);
+    t_cnt.release();
 
     // ---- which sequences go to the 2-bit kernel ------------------------------------------------------
     // Candidates by flagged granules; then the exact runs of exception bytes ("sites") from the caller's bytes of
@@ -753,7 +775,7 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
         HIPCHK(c, hipMalloc((void **)&c->d_exc_roff, n * 4));
         HIPCHK(c, hipMemcpy(c->d_exc_roff, roff.data(), n * 4, hipMemcpyHostToDevice));
     }
-    dfree(d_raw);
+    t_raw.release();
     ptot += SNK_ARENA_SLACK;
     if (ptot >= c->arena_limit)
         return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the offset range of one upload", ptot);
@@ -901,14 +923,13 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
     rc = launch_jobs(c, c->stream, c->d_jobs, nf, nb, ng, c->d_single, true);
     if (rc) return rc;
     if (!conv.empty()) {
-        uint32_t *d_ids = nullptr;
-        HIPCHK(c, hipMalloc((void **)&d_ids, conv.size() * 4));
-        HIPCHK(c, hipMemcpyAsync(d_ids, conv.data(), conv.size() * 4, hipMemcpyHostToDevice, c->stream));
+        DevTemp<uint32_t> ids;
+        HIPCHK(c, hipMalloc((void **)&ids.p, conv.size() * 4));
+        HIPCHK(c, hipMemcpyAsync(ids.p, conv.data(), conv.size() * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(snk_snap_convert_kernel, dim3((uint32_t)conv.size()), dim3(256), 0, c->stream,
-                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, c->d_lut_slot, d_ids, (uint32_t)conv.size());
+                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, c->d_lut_slot, ids.p, (uint32_t)conv.size());
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfree(d_ids);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rc = check_status(c);
@@ -936,6 +957,8 @@ int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const size_t N = (size_t)c->n, np = (size_t)(r1 - r0) * N;
     if (!np) return SNK_OK;
+    if ((uint64_t)np > 0xFFFFFFFFull)          // job numbers and output indices are 32-bit on the device
+        return fail(c, SNK_E_TOOBIG, "%zu ordered pairs in one launch (rows [%d,%d) x %zu): at most 2^32 - 1; tile the rows", np, r0, r1, N);
     size_t nf = 0, nb = 0, ng = 0;
     int rc = SNK_OK;
     if (!c->force_generic && c->n_packed == c->n && (uint64_t)c->min_len * 2u > SNK_BLOCK && (uint64_t)c->max_len * 2u < 0x7E000000ull) {
@@ -1104,6 +1127,7 @@ int snk_frames_list(snk_ctx *c, int n_items, const int32_t *ij, const uint64_t *
 int snk_pairs_ms_log(snk_ctx *c, double *ms, int cap)
 {
     if (!c || cap < 0 || (cap && !ms)) return SNK_E_ARG;
+    c->ev_logging = true;                        // from now on every launch keeps its own event pair until the next read
     const size_t n = c->ev_used;
     int k = 0;
     for (size_t t = 0; t < n; ++t) {

@@ -62,7 +62,7 @@ struct SnkTables {
     const uint8_t  *const *bytes;     // ASCII, padded (per-sequence pointers, legacy byte kernel)
     const uint8_t  *bytes_arena;      // the same ASCII data as one allocation < 4 GiB; starts with SNK_PAD zero bytes
     const uint32_t *bytes_off;        // byte offset of each sequence in the ASCII arena
-    const uint8_t  *packed_arena;     // 2-bit packed sequences, one allocation < 4 GiB; starts with 4*SNK_PAD zero bytes
+    const uint8_t  *packed_arena;     // 2-bit packed sequences, one allocation < 4 GiB; SNK_ARENA_SLACK zero bytes in front and behind
     const uint8_t  *mask_arena;       // same layout, 2 bits per base: 11 where the byte is not one of ACGT (NULL: no resident
                                       // 2-bit sequence has exceptions)
     const uint32_t *packed_off;       // byte offset of each packed sequence in the arena (0 = not packed)

@@ -130,6 +130,25 @@ def compute_distance(x, y, cxy, cyx):
 
 GPU_ALGORITHMS = ("lz4", "gzip", "zlib")
 
+_STDLIB = {"lzma": lzma.compress, "bzip2": bz2.compress, "gzip": gzip.compress, "zlib": zlib.compress}
+
+
+def ncd(seq_i, seq_j, compressor="lz4"):
+    """Normalized compression distance of two extracted sequences (``str`` or ``bytes``): the sequence-level
+    convenience BASELINE.json's north_star names ``compute_distance(seq_i, seq_j, compressor)``.  It is not in the
+    reference, whose :func:`compute_distance` takes the four sizes (kept as it is); this wrapper obtains them as
+    ref:snacc/pairwise_ncd.py:69-90 does -- ``sys.getsizeof`` of the compressed ``seq``, ``seq_i + seq_j`` and
+    ``seq_j + seq_i`` -- lz4 / gzip / zlib on the HIP backend (no CPU fallback), lzma / bzip2 with the stdlib calls
+    the reference makes.  ``KeyError`` for an unknown compressor, as ``compressed_size`` raises."""
+    _EXTENSION[compressor]
+    a, b = (bytes(s, encoding="utf-8") if isinstance(s, str) else bytes(s) for s in (seq_i, seq_j))
+    if compressor == "lz4" or (compressor in ("gzip", "zlib") and os.environ.get("SNACC_DEFLATE", "hip") != "stdlib"):
+        with _ctx_lock:
+            singles, pairs = all_pairs([a, b], compressor, ctx=_hip_context())
+        return compute_distance(int(singles[0]), int(singles[1]), int(pairs[0, 1]), int(pairs[1, 0]))
+    size = lambda data: sys.getsizeof(_STDLIB[compressor](data))      # noqa: E731
+    return compute_distance(size(a), size(b), size(a + b), size(b + a))
+
 
 def all_pairs(sequences, algorithm="lz4", ctx=None, rows=None):
     """Batched phase A + B of ref:snacc/cli.py:108-129 on the HIP backend.

@@ -120,6 +120,71 @@ def test_weighted_shards_balance_ragged_lengths():
     assert shard_rows_weighted([5.0], 3)[-1][1] == 1
 
 
+def _worker_ecoli(rank, world, port, outdir):
+    _init(rank, world, port)
+    import ecoli_like as ec
+    import oracle
+    import torch.distributed as dist
+    from oracle.loader import pairs_mt
+    from snacc_amd.distributed import all_pairs_sharded, init_process_group, lz4_row_weights
+    init_process_group("gloo")
+    seqs = [ec.expected_sequence(ec.records(i, ec.make_genome(oracle, i, scale=1000)), True) for i in range(ec.N_GENOMES)]
+    calls = []
+
+    def rows_fn(r0, r1):
+        calls.append((r0, r1))
+        return pairs_mt(seqs, r0, r1, 2)
+
+    # the row weights are those of the FULL-SIZE set (what a rank of the real run computes from ctx.lengths())
+    full = all_pairs_sharded(ec.N_GENOMES, rows_fn, weights=lz4_row_weights(ec.lengths()), tile_rows=16)
+    np.save(os.path.join(outdir, f"full_{rank}.npy"), full)
+    np.save(os.path.join(outdir, f"rows_{rank}.npy"), np.array(calls, dtype=np.int64).reshape(-1, 2))
+    dist.destroy_process_group()
+
+
+def test_config5_set_through_the_sharded_split_world3(tmp_path):
+    """BASELINE.json configs[4] (92 genomes, row-sharded): the 92 lengths of the stand-in set (tests/ecoli_like.py)
+    cut into work-balanced row blocks for 3 ranks, every rank's tiles all-gathered (gloo), the assembled matrix
+    equal to the single-process one on every rank.  Sizes come from the set at 1/1000 scale (the oracle at full
+    size is the GPU test's job); the weights are those of the full-size lengths."""
+    import ecoli_like as ec
+    import oracle
+    from oracle.loader import pairs_mt
+    from snacc_amd.distributed import lz4_row_weights, shard_rows_weighted
+    world, n = 3, ec.N_GENOMES
+    port = 33500 + (os.getpid() * 5) % 2000
+    mp.spawn(_worker_ecoli, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    w = lz4_row_weights(ec.lengths())
+    blocks = shard_rows_weighted(w, world)
+    assert blocks[0][0] == 0 and blocks[-1][1] == n and all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+    share = np.array([w[a:b].sum() for a, b in blocks])
+    assert share.max() <= w.sum() / world + w.max()                      # no rank more than one row above the ideal share
+    assert share.max() / share.min() < 1.10
+    seqs = [ec.expected_sequence(ec.records(i, ec.make_genome(oracle, i, scale=1000)), True) for i in range(n)]
+    want = pairs_mt(seqs, 0, n, 2)
+    covered = []
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
+        for a, b in np.load(tmp_path / f"rows_{r}.npy"):
+            assert blocks[r][0] <= a < b <= blocks[r][1] and b - a <= 16
+            covered += list(range(a, b))
+    assert sorted(covered) == list(range(n))
+
+
+def test_config5_set_files_read_natively_equal_the_python_statement(tmp_path):
+    """The stand-in set's FASTA files (multi-record, N runs, IUPAC codes, a lower-case stretch) through the native
+    reader with per-record reverse complement = the Python statement of ref:snacc/pairwise_ncd.py:29-36 (1/100 scale)."""
+    import ecoli_like as ec
+    import oracle
+    from snacc_amd import hip_backend
+    for i in (0, 7, 33, 35, 70, 91):
+        recs = ec.records(i, ec.make_genome(oracle, i, scale=100))
+        p = tmp_path / f"g{i:02d}.fna"
+        ec.write_fasta_fast(p, recs)
+        for rc in (False, True):
+            assert hip_backend.fasta_extract(p, rc) == bytes(ec.expected_sequence(recs, rc)), (i, rc)
+
+
 class _CheckerContext:
     """Stands in for HipContext in cli.gpu_matrix: sizes from the oracle, written where the caller says."""
     def __init__(self, device):
@@ -129,10 +194,21 @@ class _CheckerContext:
         self.seqs = []
         self.closed = False
 
+    arena_limit = None           # residues one upload may hold (tests of the blocked path set it)
+
     def upload_fasta(self, paths, reverse_complement=False):
         from snacc_amd import fasta
-        self.seqs = [np.frombuffer(fasta.read_sequence(p, reverse_complement).encode(), dtype=np.uint8) for p in paths]
+        from snacc_amd.hip_backend import ArenaTooBig
+        seqs = [np.frombuffer(fasta.read_sequence(p, reverse_complement).encode(), dtype=np.uint8) for p in paths]
+        if self.arena_limit is not None and sum(len(s) + 128 for s in seqs) >= self.arena_limit:
+            raise ArenaTooBig("ASCII arena exceeds the offset range of one upload")
+        self.seqs = seqs
         self.n = len(self.seqs)
+        self.uploads = getattr(self, "uploads", 0) + 1
+
+    def pairs_list(self, ij):
+        from oracle.loader import pairs_list_mt
+        return pairs_list_mt(self.seqs, np.array(ij, dtype=np.int32), 2)
 
     def lengths(self):
         return np.array([len(s) for s in self.seqs], dtype=np.uint64)
@@ -153,15 +229,18 @@ class _CheckerContext:
         self.closed = True
 
 
-def _worker_cli(rank, world, port, fadir, outdir):
+def _worker_cli(rank, world, port, fadir, outdir, arena_limit=None):
     _init(rank, world, port)
     import torch.distributed as dist
     from click.testing import CliRunner
     from snacc_amd import cli as cli_mod
     made = []
+    if arena_limit:
+        os.environ["SNACC_ARENA_LIMIT"] = str(arena_limit)
 
     def factory(dev):
         made.append(_CheckerContext(dev))
+        made[-1].arena_limit = arena_limit
         return made[-1]
 
     real = cli_mod.gpu_matrix
@@ -171,6 +250,7 @@ def _worker_cli(rank, world, port, fadir, outdir):
     res = CliRunner().invoke(cli_mod.cli, [fadir, "-o", str(out), "-c", "lz4", "--no-show-progress", "--no-log"])
     Path(outdir, f"cli_{rank}.txt").write_text(f"{res.exit_code}\n{int(out.exists())}\n{int(dist.is_initialized())}\n"
                                                f"{int(made[0].closed)}\n{res.output}\n{res.exception!r}")
+    Path(outdir, f"uploads_{rank}.txt").write_text(str(getattr(made[0], "uploads", 0)))
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -195,6 +275,62 @@ def test_cli_multi_rank_only_rank0_reports_and_writes(tmp_path, world):
         assert ("Compressing pairs..." in "\n".join(output)) == (r == 0)
     got = np.loadtxt(tmp_path / "out_0.csv", delimiter=",", skiprows=1, usecols=range(1, 6))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cli_multi_rank_set_beyond_one_upload_is_sharded_by_group_pairs(tmp_path, world):
+    """A set that does not fit one upload (ArenaTooBig) under torchrun: the group pairs of
+    snacc_amd.cli.blocked_sizes are dealt over the ranks (no rank raises, no rank does all the uploads), the two
+    result arrays are summed over the ranks and rank 0 writes the same CSV as a single upload gives."""
+    import oracle
+    from conftest import write_fasta
+    from snacc_amd.matrix import ncd_matrix
+    fadir = tmp_path / "fa"
+    fadir.mkdir()
+    seqs = _seqs(7, 20000)
+    for k, sq in enumerate(seqs):
+        write_fasta(fadir / f"g{k}.fasta", [("r", bytes(sq).decode())])
+    port = 35500 + (os.getpid() * 3 + world) % 2000
+    # 7 files of ~21-27 kB against a limit of 110 kB: groups of two files (45 % of the limit), 10 group pairs
+    mp.spawn(_worker_cli, args=(world, port, str(fadir), str(tmp_path), 110_000), nprocs=world, join=True)
+    singles = np.array([oracle.lz4f_size(s) for s in seqs], dtype=np.int64) + 33
+    pairs = np.array([[oracle.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.int64) + 33
+    want = ncd_matrix(singles, pairs)
+    uploads = []
+    for r in range(world):
+        code, wrote, still_init, closed, *output = (tmp_path / f"cli_{r}.txt").read_text().split("\n")
+        assert code == "0" and still_init == "0" and closed == "1", (r, output)
+        assert wrote == ("1" if r == 0 else "0")
+        uploads.append(int((tmp_path / f"uploads_{r}.txt").read_text()))
+    assert sum(uploads) >= 10 and max(uploads) < sum(uploads)           # every rank took a share of the group pairs
+    got = np.loadtxt(tmp_path / "out_0.csv", delimiter=",", skiprows=1, usecols=range(1, 8))
+    assert np.array_equal(got, want)
+
+
+def test_blocked_sizes_splits_an_upload_that_still_does_not_fit(tmp_path):
+    """Groups are sized from file sizes; when an upload of two groups still exceeds the limit (arena padding under a
+    small limit) it is split in halves, and a single pair that cannot fit ends with a message, not a traceback."""
+    import click
+    import oracle
+    from conftest import write_fasta
+    from snacc_amd.cli import blocked_sizes
+    seqs = _seqs(6, 9000)
+    files = []
+    for k, sq in enumerate(seqs):
+        files.append(tmp_path / f"g{k}.fasta")
+        write_fasta(files[-1], [("r", bytes(sq).decode())])
+    ctx = _CheckerContext(0)
+    ctx.arena_limit = 37_000                                               # any two files fit, the four of two groups do not
+    os.environ["SNACC_ARENA_LIMIT"] = "70000"                               # ... but the groups are cut for 31 kB of file each
+    try:
+        singles, pairs = blocked_sizes(ctx, files, "lz4", False)
+    finally:
+        del os.environ["SNACC_ARENA_LIMIT"]
+    assert singles.tolist() == [oracle.lz4f_size(s) + 33 for s in seqs]
+    assert pairs.tolist() == [[oracle.lz4f_size_pair(a, b) + 33 for b in seqs] for a in seqs]
+    ctx.arena_limit = 15_000                                               # not even one pair fits
+    with pytest.raises(click.ClickException, match="do not fit one upload"):
+        blocked_sizes(ctx, files, "lz4", False)
 
 
 def test_failed_rendezvous_exits_non_zero(tmp_path):

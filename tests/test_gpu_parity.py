@@ -405,6 +405,7 @@ def test_interleaved_async_launches_and_schedules(hip, oracle_mod):
         for dyn in (0, 1):
             with hip.HipContext(0, fast_dynamic=dyn, fast_lanes=3, fast_waves=2) as ctx:
                 ctx.upload(seqs)
+                ctx.pairs_ms_log()                       # the per-launch log starts at the first call
                 s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
                 t1 = torch.zeros((4, n), dtype=torch.int32, device=dev)
                 t2 = torch.zeros((n - 4, n), dtype=torch.int32, device=dev)
@@ -452,21 +453,33 @@ def test_sets_beyond_one_upload_are_processed_in_blocks(hip, oracle_mod, tmp_pat
     monkeypatch.delenv("SNACC_ARENA_LIMIT", raising=False)
 
 
-def test_python_api_single_items(hip, golden):
+def test_python_api_single_items(hip, golden, tmp_path):
     """compressed_size(path | (path, path), "lz4") -- the reference's granularity."""
-    from pathlib import Path
     from snacc_amd import compressed_size
-    p = Path(__file__).parent / "golden" / "sample_crlf.fa"
+    p = tmp_path / "sample_crlf.fa"
     with open(p, "w", newline="") as f:
         f.write(">derice\r\nACTGACTAGCTAGCTAACTG\r\n>sanka\r\nGCATCGTAGCTAGCTACGAT\r\n"
                 ">junior\r\nCATCGATCGTACGTACGTAG\r\n>yul\r\nATCGATCGATCGTACGATCG")
-    try:
-        g = golden["sample_fa"]
-        assert compressed_size(p, "lz4") == (p, g["sizes_single"]["lz4"])
-        assert compressed_size((p, p), "lz4") == ((p, p), g["sizes_selfpair"]["lz4"])
-        assert compressed_size(p, "lz4", reverse_complement=True)[1] == g["sizes_single_rc_lz4"]
-    finally:
-        p.unlink()
+    g = golden["sample_fa"]
+    assert compressed_size(p, "lz4") == (p, g["sizes_single"]["lz4"])
+    assert compressed_size((p, p), "lz4") == ((p, p), g["sizes_selfpair"]["lz4"])
+    assert compressed_size(p, "lz4", reverse_complement=True)[1] == g["sizes_single_rc_lz4"]
+
+
+def test_sequence_level_ncd_wrapper(hip, oracle_mod):
+    """north_star's ``compute_distance(seq_i, seq_j, compressor)`` convenience: ``snacc_amd.ncd`` on two extracted
+    sequences = the reference's four-integer formula (ref:snacc/pairwise_ncd.py:93-111) on the sizes of ref:...:69-90."""
+    from snacc_amd import compute_distance, ncd
+    o = oracle_mod
+    x, y = o.lcg_genome(61, 90_000), o.lcg_mutant(o.lcg_genome(61, 90_000), 5)
+    sx, sy = o.lz4f_size(x) + 33, o.lz4f_size(y) + 33
+    want = compute_distance(sx, sy, o.lz4f_size_pair(x, y) + 33, o.lz4f_size_pair(y, x) + 33)
+    assert ncd(bytes(x), bytes(y), "lz4") == want
+    assert ncd(bytes(x).decode(), bytes(y).decode()) == want            # str or bytes; lz4 is the default here
+    import gzip
+    gx, gy = bytes(x[:5000]), bytes(y[:5000])
+    c = lambda b: len(gzip.compress(b)) + 33                            # noqa: E731
+    assert ncd(gx, gy, "gzip") == compute_distance(c(gx), c(gy), c(gx + gy), c(gy + gx))
 
 
 def test_python_api_from_a_thread_pool(hip, oracle_mod, tmp_path):
@@ -618,6 +631,48 @@ def test_config5_substitute_5mbp_reverse_complement_cli(hip, oracle_mod, tmp_pat
     pairs = pairs_mt([np.frombuffer(s_, dtype=np.uint8) for s_ in seqs_rc], 0, 10, _threads()).astype(np.int64) + 33
     want = ncd_matrix(singles, pairs)
     assert np.array_equal(got, want)                # repr round-trips: exact, well inside the 1e-6 of north_star
+
+
+def test_config5_at_its_own_size_92_genomes_reverse_complement_cli(hip, oracle_mod, tmp_path, monkeypatch):
+    """BASELINE.json configs[4] at its real size on one GPU: 92 genomes of ~5 Mbp (tests/ecoli_like.py: 2 % mutants
+    of four ancestors, 1 .. 4 records per file, N runs, IUPAC codes, one soft-masked stretch), `snacc -c lz4 -r`
+    through the CLI (native FASTA ingest, per-record reverse complement, one upload, 92 x 92 ordered pairs on the
+    GPU).  First row, first column, the diagonal and a sample of > 5 % of the ordered pairs are compared with the
+    oracle, as NCD values (exact: computed from equal integers) -- ref:snacc/pairwise_ncd.py:29-36, ref:snacc/cli.py:120-136."""
+    import ecoli_like as ec
+    from click.testing import CliRunner
+    from oracle.loader import pairs_list_mt
+    from snacc_amd.cli import cli
+    from snacc_amd.pairwise_ncd import compute_distance
+    o = oracle_mod
+    n = ec.N_GENOMES
+    anc = [o.lcg_genome(7000 + a, ec.ancestor_length(a)) for a in range(ec.N_ANCESTORS)]
+    d = tmp_path / "st131"
+    d.mkdir()
+    seqs = []
+    for i in range(n):
+        recs = ec.records(i, ec.make_genome(o, i, ancestors=anc))
+        ec.write_fasta_fast(d / f"g{i:02d}.fna", recs)
+        seqs.append(ec.expected_sequence(recs, reverse_complement=True))
+    assert [len(s) for s in seqs] == ec.lengths() and sum(len(s) for s in seqs) > 440_000_000
+    out = tmp_path / "out.csv"
+    monkeypatch.chdir(tmp_path)
+    res = CliRunner().invoke(cli, [str(d), "-o", str(out), "-c", "lz4", "-r", "--no-show-progress", "--no-log"])
+    assert res.exit_code == 0, res.output
+    got = np.loadtxt(out, delimiter=",", skiprows=1, usecols=range(1, n + 1))
+    assert got.shape == (n, n) and np.array_equal(got, got.T)
+    rng = np.random.default_rng(92)
+    cells = {(0, j) for j in range(n)} | {(i, i) for i in range(n)}
+    while len(cells) < 2 * n - 1 + 230:                         # + 230 cells = 460 ordered pairs > 5 % of 8464
+        i, j = (int(v) for v in rng.integers(0, n, 2))
+        cells.add((min(i, j), max(i, j)))
+    cells = sorted(cells)
+    ij = np.array([(i, j) for i, j in cells] + [(j, i) for i, j in cells], dtype=np.int32)
+    sz = pairs_list_mt(seqs, ij, _threads()).astype(np.int64) + 33
+    single = {g: o.lz4f_size(seqs[g]) + 33 for g in {int(v) for v in ij.ravel()}}
+    for k, (i, j) in enumerate(cells):
+        want = compute_distance(single[i], single[j], int(sz[k]), int(sz[len(cells) + k]))
+        assert got[i, j] == want, (i, j, got[i, j], want)
 
 
 def test_edge_cases_single_sequence_and_duplicates(hip, oracle_mod):

@@ -91,6 +91,28 @@ def test_compute_distance_kats(golden):
     assert compute_distance(1174721, 1173133, 1242873, 1242873) == 0.05936728806244206
 
 
+def test_sequence_level_ncd_wrapper_stdlib_codecs(monkeypatch):
+    """``ncd(seq_i, seq_j, compressor)`` (north_star's convenience; not in the reference): the four sizes as
+    ref:snacc/pairwise_ncd.py:69-90 obtains them, then the reference's formula -- lzma / bzip2 here; lz4 on the GPU box."""
+    import bz2
+    import lzma
+    import sys as _sys
+    import snacc
+    from snacc_amd import compute_distance, ncd
+    assert snacc.ncd is ncd
+    x, y = "ACGTTGCAAGGCTA" * 300, "ACGTTGCTAGGCTAACG" * 250
+    for name, fn in (("lzma", lzma.compress), ("bzip2", bz2.compress)):
+        c = lambda s: _sys.getsizeof(fn(s.encode()))                     # noqa: E731
+        assert ncd(x, y, name) == compute_distance(c(x), c(y), c(x + y), c(y + x))
+        assert ncd(x.encode(), y.encode(), name) == ncd(x, y, name)
+    monkeypatch.setenv("SNACC_DEFLATE", "stdlib")                           # the reference's own gzip call, asked for explicitly
+    import gzip
+    c = lambda s: _sys.getsizeof(gzip.compress(s.encode()))              # noqa: E731
+    assert ncd(x, y, "gzip") == compute_distance(c(x), c(y), c(x + y), c(y + x))
+    with pytest.raises(KeyError):
+        ncd(x, y, "zstd")
+
+
 def test_ncd_matrix_equals_scalar_formula():
     rng = np.random.default_rng(3)
     n = 17

@@ -2,7 +2,7 @@
 # Dev aid (GPU box): HBM traffic of one snk_fast_kernel launch of the bench shape, as the microarch guide prescribes
 # (separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE doubled on gfx950).  Writes OUT.json.
 # Usage: tools/gpu_traffic.sh OUT.json COMMIT [N L ROWS]
-OUT=${1:-gpurun_out/r02_pmc_traffic.json}; COMMIT=${2:-unknown}; N=${3:-1024}; L=${4:-1000000}; R=${5:-84}
+OUT=${1:-gpurun_out/r02_pmc_traffic.json}; COMMIT=${2:?COMMIT (tools/commit_id.sh, run in the build container) is required}; N=${3:-1024}; L=${4:-1000000}; R=${5:-84}
 export TMPDIR=/tmp
 D=$(dirname "$OUT")/traffic_raw; mkdir -p "$D"
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -2,7 +2,7 @@
 # Dev aid (GPU box): HBM traffic of one gzip / zlib bench step (86 016 pair jobs of dfl_parse_kernel*), as the microarch
 # guide prescribes (separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE doubled on gfx950).
 # Usage: tools/gpu_traffic_dfl.sh OUT.json COMMIT [gzip|zlib]
-OUT=${1:-gpurun_out/pmc_traffic_gzip.json}; COMMIT=${2:-unknown}; CODEC=${3:-gzip}
+OUT=${1:-gpurun_out/pmc_traffic_gzip.json}; COMMIT=${2:?COMMIT (tools/commit_id.sh, run in the build container) is required}; CODEC=${3:-gzip}
 export TMPDIR=/tmp
 D=$(dirname "$OUT")/traffic_raw_dfl; mkdir -p "$D"
 for c in FETCH_SIZE WRITE_SIZE; do
