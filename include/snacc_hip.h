@@ -126,7 +126,7 @@ int snk_pairs(snk_ctx *ctx, int row_begin, int row_end, uint32_t *sizes /* host 
  * `d_sizes` ((row_end-row_begin)*n_seq elements), e.g. a torch tensor that is
  * then all-gathered over RCCL.  Does not synchronise.  The device-side status
  * word is checked by the next blocking call or by snk_sync().  One call covers at most
- * 2^32 - 1 ordered pairs ((row_end-row_begin)*n_seq; SNK_E_TOOBIG beyond: tile the rows, as
+ * 0xFFF00000 ordered pairs ((row_end-row_begin)*n_seq; SNK_E_TOOBIG beyond: tile the rows, as
  * snk_pairs does). */
 int snk_pairs_device(snk_ctx *ctx, int row_begin, int row_end, void *d_sizes, void *hip_stream);
 

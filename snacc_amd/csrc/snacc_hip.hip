@@ -34,6 +34,10 @@ struct snk_ctx_impl {
     int fast_dynamic = -1;           // -1 auto (by length spread), 0 static round robin, 1 atomic queue
     bool dense_tile = false;         // the last build_jobs found every pair of the tile fit for the 2-bit kernel
     hipEvent_t jobs_busy = nullptr;  // last launch that reads d_jobs: waited for before the list is rewritten
+    uint32_t *d_far = nullptr; size_t far_bytes = 0;     // tables of the 2-bit kernel's far chains (one set per context)
+    hipEvent_t far_busy = nullptr; bool far_in_flight = false;   // ... in use until the launch that got them ends
+    int far_lanes = 0, far_waves = 4; // far_lanes 0 = no far chains
+    int far_stop_pct = 140;          // far waves take no new jobs once fewer than this % of (LDS chains of the launch) jobs are left
     hipEvent_t ovf_busy = nullptr;   // last 2-bit launch with exceptions: its chains' overflow tables (one set per context) are
     bool ovf_in_flight = false;      // in use until it ends -- the next such launch waits for it on its own stream
     std::string err;
@@ -121,6 +125,7 @@ void free_sequences(snk_ctx_impl *c)
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
     dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0; c->ovf_in_flight = false;
     dfree(c->d_exc_runs); dfree(c->d_exc_roff);
+    dfree(c->d_far); c->far_bytes = 0; c->far_in_flight = false;
     c->has_exc.clear(); c->any_exc = false;
     c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
     if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
@@ -228,6 +233,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         SnkFastGrid G;
         const bool dense = tile && tile->rows > 0;
+        // far chains (tables in global memory, extra waves): pair launches of pure-ACGT sets that fill the card
+        uint32_t far_waves = (!exc && !singles && c->far_lanes > 0) ? (uint32_t)c->far_waves : 0u;
+        if (far_waves && (waves + far_waves > 8u || n_fast < (size_t)4 * chains * (size_t)std::max(c->n_cus, 1))) far_waves = 0u;
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
@@ -245,11 +253,27 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         // persistent launch: one workgroup per compute unit at most (the LDS admits one), waves walk the batches
         uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
         if (c->n_cus > 0 && grid > (uint32_t)c->n_cus) grid = (uint32_t)c->n_cus;
-        const bool dynamic = c->fast_dynamic < 0 ? (singles || (tile && tile->ragged)) : c->fast_dynamic != 0;
+        // (far waves are slower per chain than LDS waves: only the atomic queue keeps both kinds busy)
+        const bool dynamic = far_waves ? true : c->fast_dynamic < 0 ? (singles || (tile && tile->ragged)) : c->fast_dynamic != 0;
         if (dynamic) {       // ragged lengths: later batches come from an atomic counter that starts behind the waves' first ones
             if (dense) G.yorder = c->d_yorder;               // ... and the longest suffixes go out first
             G.queue = c->d_queue + (c->queue_next++ & 63u);
-            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.queue, (int)(grid * waves), 1, st));
+            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)G.queue, 0, 1, st));
+        }
+        if (far_waves) {
+            const size_t need = (size_t)grid * far_waves * (size_t)c->far_lanes * SNK_FSLOTS * sizeof(uint32_t);
+            if (need > c->far_bytes) {
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (c->far_in_flight) { HIPCHK(c, hipEventSynchronize(c->far_busy)); c->far_in_flight = false; }
+                dfree(c->d_far);
+                HIPCHK(c, hipMalloc((void **)&c->d_far, need));
+                c->far_bytes = need;
+            }
+            // one set of far tables per context: launches that use it run one after the other, whatever their streams
+            if (c->far_in_flight) HIPCHK(c, hipStreamWaitEvent(st, c->far_busy, 0));
+            G.far_tab = c->d_far; G.lds_waves = waves; G.far_lanes = (uint32_t)c->far_lanes;
+            // a far chain takes ~1.4x as long over a job as an LDS chain: below ~1.4 jobs per LDS chain left, the LDS waves finish first
+            G.far_stop = (uint32_t)(((uint64_t)grid * chains * (uint64_t)c->far_stop_pct) / 100u);
         }
         if (exc) {
             const size_t need = (size_t)grid * chains * 4096u * sizeof(uint32_t);       // one overflow table per resident chain
@@ -273,10 +297,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         else if (singles)
             hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (c->fast_asm)
-            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
         else
-            hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
+        if (far_waves) { HIPCHK(c, hipEventRecord(c->far_busy, st)); c->far_in_flight = true; }
         if (exc) { HIPCHK(c, hipEventRecord(c->ovf_busy, st)); c->ovf_in_flight = true; }
     }
     if (n_bytes && c->compact_ok) {
@@ -493,6 +518,7 @@ int snk_ctx_create(int device, snk_ctx **out)
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRCHK(hipEventCreate(&c->jobs_busy));
     CRCHK(hipEventCreateWithFlags(&c->ovf_busy, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&c->far_busy, hipEventDisableTiming));
     {
         hipDeviceProp_t prop;
         CRCHK(hipGetDeviceProperties(&prop, device));
@@ -531,6 +557,7 @@ void snk_ctx_destroy(snk_ctx *c)
     for (auto &e : c->ev_log) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->jobs_busy) (void)hipEventDestroy(c->jobs_busy);
     if (c->ovf_busy) (void)hipEventDestroy(c->ovf_busy);
+    if (c->far_busy) (void)hipEventDestroy(c->far_busy);
     dfree(c->d_queue);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -546,6 +573,15 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "fast_waves") {
         if (value < 1 || value > 8) return fail(c, SNK_E_ARG, "fast_waves must be 1..8");
         c->fast_waves = (int)value;
+    } else if (k == "far_lanes") {
+        if (value < 0 || value > 64) return fail(c, SNK_E_ARG, "far_lanes must be 0 (no far chains) or 1..64");
+        c->far_lanes = (int)value;
+    } else if (k == "far_waves") {
+        if (value < 1 || value > 7) return fail(c, SNK_E_ARG, "far_waves must be 1..7");
+        c->far_waves = (int)value;
+    } else if (k == "far_stop_pct") {
+        if (value < 0 || value > 10000) return fail(c, SNK_E_ARG, "far_stop_pct must be 0..10000");
+        c->far_stop_pct = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
     } else if (k == "exc_limit") {
@@ -957,8 +993,8 @@ int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const size_t N = (size_t)c->n, np = (size_t)(r1 - r0) * N;
     if (!np) return SNK_OK;
-    if ((uint64_t)np > 0xFFFFFFFFull)          // job numbers and output indices are 32-bit on the device
-        return fail(c, SNK_E_TOOBIG, "%zu ordered pairs in one launch (rows [%d,%d) x %zu): at most 2^32 - 1; tile the rows", np, r0, r1, N);
+    if ((uint64_t)np > 0xFFF00000ull)          // job numbers and output indices are 32-bit on the device (and the job counter overshoots a little)
+        return fail(c, SNK_E_TOOBIG, "%zu ordered pairs in one launch (rows [%d,%d) x %zu): at most 0xFFF00000; tile the rows", np, r0, r1, N);
     size_t nf = 0, nb = 0, ng = 0;
     int rc = SNK_OK;
     if (!c->force_generic && c->n_packed == c->n && (uint64_t)c->min_len * 2u > SNK_BLOCK && (uint64_t)c->max_len * 2u < 0x7E000000ull) {
@@ -1064,9 +1100,9 @@ int snk_debug_trace(unsigned int from, unsigned int *out /* [1 + 4*4096] */, int
 
 #ifdef SNK_STATS
 /* diagnostic build only (not part of the shipped ABI): read and clear the event counters */
-int snk_debug_stats(unsigned long long *out16 /* [32] */)
+int snk_debug_stats(unsigned long long *out16 /* [64] */)
 {
-    unsigned long long zero[32] = { 0 };
+    unsigned long long zero[64] = { 0 };
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(snk_stats), sizeof zero) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(snk_stats), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }

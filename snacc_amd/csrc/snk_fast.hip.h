@@ -113,7 +113,7 @@ struct SnkFastLane {
 // entries, 15 trips of the C++ loop (same trips as the asm loop's), 16..22 why lanes asked for service, 24 finish,
 // 25 / 26 general-probe rounds between two loop entries (cycles / rounds), 27 loop prologue.
 #ifdef SNK_STATS
-__device__ unsigned long long snk_stats[32];
+__device__ unsigned long long snk_stats[64];      // [32..63]: the same account for the far waves
 #define SNK_COUNT(i) atomicAdd(&snk_stats[i], 1ull)
 // per-lane events of the general path (one atomic per probe and lane: they slow a run with many exception sites down
 // several times over; -DSNK_STATS=2 counts them, the plain stats build keeps the cycle account undistorted)
@@ -124,7 +124,7 @@ __device__ unsigned long long snk_stats[32];
 #endif
 // the cycle account is kept in registers and added to snk_stats once, when the wave ends (atomics on the way would
 // change what they measure): every lane carries the same numbers, lane 0 reports them
-struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top; unsigned int entries, rounds; };
+struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top; unsigned int entries, rounds, jobs; };
 #define SNK_PROF_ARG , SnkProf &P
 #define SNK_PROF_PASS , P
 #else
@@ -288,8 +288,10 @@ __device__ __forceinline__ void snk_exc_finish(SnkFastLane &L, uint32_t cur, uin
 
 // Rare path (once per 64 KiB): close the finished block, age the table, open the next block.
 // Returns true when the frame is complete (size written).
-template <bool EXC>
-__device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+// FAR (chains of the extra waves, see "Chains beyond the LDS" below): the table is gt[896], absolute positions as u32 in
+// global memory -- no bitmap, no aging (a candidate is in range when cur - e <= 65535); tbl / bm are unused then.
+template <bool EXC, bool FAR>
+__device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm, uint32_t *gt,
                                                  const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
     if (L.in_block) {
@@ -306,7 +308,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
         L.endcode = 0u;
     }
     for (;;) {
-        if (L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
+        if (!FAR && L.snap != 0 && L.pos == L.spos && L.spos != 0u) {
             // prefix snapshot: absolute positions; entries older than one block -> 0 (too far for good)
             uint32_t *dst = T.snap_fast + (size_t)L.xi * SNK_FSLOTS;
             for (uint32_t t = 0; t < SNK_FSLOTS; ++t) {
@@ -331,7 +333,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             L.pos = L.iend;
             continue;
         }
-        if (!L.first) {
+        if (!FAR && !L.first) {
             // age the table: entries not written during the block just finished are dead
             for (uint32_t wi = 0; wi < SNK_FBMWORDS; ++wi) {
                 uint32_t z = ~bm[wi];
@@ -350,6 +352,9 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             snk_exc_seek(L, L.pos);
             if (!snk_exc_clean(L, L.pos)) L.mask_until = L.pos + 65536u;      // (an entry is read at most 65 535 bytes further on)
             snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, L.pos)), L.pos);
+        } else if (FAR) {
+            const uint32_t w0 = snk_fetch32(L.s, L.pos);
+            gt[slot[(w0 >> 8) & 1023u]] = L.pos;
         } else {
             const uint32_t w0 = snk_fetch32(L.s, L.pos);
             const uint32_t s0 = slot[(w0 >> 8) & 1023u];
@@ -418,13 +423,13 @@ __device__ __forceinline__ void snk_fast_finish(SnkFastLane &L, uint32_t cur, ui
 // One probe the general way (any source, any state): opens and closes blocks, walks the seam and
 // the stream start, serves lanes the steady loop has handed over.  Returns true when the lane's
 // frame is complete.  Rare path: block edges, seams, service -- speed is irrelevant here.
-template <bool EXC>
-__device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+template <bool EXC, bool FAR>
+__device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm, uint32_t *gt,
                                               const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur;
     if (cur + L.step > L.mfl1)                               // block end, bail-out, or not started yet
-        return snk_fast_block_step<EXC>(L, T, tbl, bm, slot, out, status);
+        return snk_fast_block_step<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status);
     if (EXC) {                                               // liblz4's order on the real bytes: put(cur-2), get(cur), put(cur)
         SNK_COUNT_HEAVY(1);
         snk_exc_seek(L, cur);
@@ -446,6 +451,13 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
     const uint32_t s1 = slot[(wc >> 8) & 1023u];             // slot of the 5-mer at cur
     uint32_t s2 = slot[(wc >> 4) & 1023u];                   // slot of the 5-mer at cur-2
     s2 = L.pending ? s2 : (SNK_FSLOTS - 1u);                 // nothing owed: aim the put at the unused slot
+    if (FAR) {                                               // liblz4's own order on absolute positions
+        gt[s2] = cur - 2u;
+        const uint32_t e = gt[s1];
+        gt[s1] = cur;
+        snk_fast_finish(L, cur, e, cur - e <= SNK_MAXDIST);
+        return false;
+    }
     const uint32_t e = tbl[s1];
     const uint32_t bw = bm[s1 >> 5];
     const uint32_t c = cur - L.base;                         // offset from the virtual base
@@ -539,6 +551,52 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_bfe_u32 %[t], v94, %[s1], 1\n\t" \
     "v_lshl_add_u32 %[t], %[t], 16, v91\n\t" \
     "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t" SNK_PADB
+// FAR chains (tables in global memory, u32 absolute positions).  As in the LDS loop the read of slot(cur) heads the chain
+// and the case slot(cur-2) == slot(cur) is patched in by a select; the two puts are fire-and-forget stores issued AFTER
+// the table load has returned (behind the candidate and refill loads): a store to a line with a read miss in flight stalls
+// the CU's whole L1 pipeline until the miss returns (TCP_PENDING_STALL_CYCLES, measured: profiles/r03_far_pmc.json).
+// vmcnt counts loads and stores in program order.  t is clamped to [0, 131071]: every candidate address stays inside the
+// arena whatever the entry holds (a dead or stale entry gives t <= 0 -> never valid).
+#ifndef SNK_FAR_LOADMOD
+#define SNK_FAR_LOADMOD "sc1"      /* device scope: served by the L2, the line is not kept in the CU's L1 (which the windows of y live in) */
+#endif
+#define SNK_STEADY_TABLE_FAR \
+    "1:\n\t" \
+    "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur */ \
+    "v_lshl_add_u32 v90, %[s1], 2, %[gtb]\n\t" \
+    "global_load_dword v91, v90, %[ftab] " SNK_FAR_LOADMOD "\n\t" \
+    "v_add_u32_e32 v96, %[vbm2], %[c]\n\t"              /* absolute cur - 2 */ \
+    "v_add_u32_e32 v99, 0xfffe, %[c]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot */ \
+    "v_lshl_add_u32 v95, %[s2], 2, %[gtb]\n\t" \
+    "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
+    "v_add_u32_e32 v97, 2, v96\n\t" \
+    "v_add_u32_e32 v112, 1, %[c]\n\t" \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "v_sub_u32_e32 %[t], v91, %[T0]\n\t" \
+    "v_med3_i32 %[t], %[t], 0, %[k17]\n\t" \
+    "v_cndmask_b32_e32 %[t], %[t], v99, vcc\n\t"
+#if defined(SNK_FAR_DIAG) && SNK_FAR_DIAG == 1      /* diagnostic build only: no puts (wrong sizes; what the stores cost the CU) */
+#define SNK_STEADY_STORES_FAR "v_mov_b32_e32 v122, v95\n\tv_mov_b32_e32 v122, v90\n\t"
+#define SNK_FAR_W1 "1"
+#define SNK_FAR_W0 "0"
+#elif defined(SNK_FAR_DIAG) && SNK_FAR_DIAG == 2    /* diagnostic build only: the puts as atomic swaps without return */
+#define SNK_STEADY_STORES_FAR \
+    "global_atomic_swap v95, v96, %[ftab]\n\t" \
+    "global_atomic_swap v90, v97, %[ftab]\n\t"
+#define SNK_FAR_W1 "3"
+#define SNK_FAR_W0 "2"
+#else
+#ifndef SNK_FAR_STOREMOD
+#define SNK_FAR_STOREMOD ""
+#endif
+#define SNK_STEADY_STORES_FAR \
+    "global_store_dword v95, v96, %[ftab] " SNK_FAR_STOREMOD "\n\t"          /* put(cur-2), then put(cur): same slot -> cur stays */ \
+    "global_store_dword v90, v97, %[ftab] " SNK_FAR_STOREMOD "\n\t"
+#define SNK_FAR_W1 "3"                                    /* the two puts are behind the loads in the count */
+#define SNK_FAR_W0 "2"
+#endif
 // candidate window address: v104 = arena byte offset, v103 = position whose low 2 bits give the phase
 #define SNK_STEADY_ADDR_DUAL \
     "v_sub_u32_e32 v100, %[t], %[sx]\n\t" \
@@ -552,14 +610,24 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_lshrrev_b32_e32 v104, 2, %[t]\n\t" \
     "v_add_u32_e32 v104, v104, %[yoffB]\n\t"
 // shadow of the candidate load: commit of the previous probe, refill, validity (PH = phase register)
+// diagnostic build only (-DSNK_PAD_LOAD=k): k redundant copies of the refill load per trip -- what one more L1 access per
+// lane and trip costs (tools/gpu_padload.sh)
+#ifdef SNK_PAD_LOAD
+#define SNK_PADLOAD ".rept " SNK_STR(SNK_PAD_LOAD) "\n\tglobal_load_dword v122, %[nxoff], %[arena]\n\t.endr\n\t"
+#define SNK_PADLOAD_W1 SNK_STR(SNK_PAD_LOAD_P1)
+#define SNK_STEADY_SHADOW(PH) SNK_STEADY_SHADOW_XX(PH, "", SNK_PADLOAD)
+#else
 #define SNK_STEADY_SHADOW(PH) SNK_STEADY_SHADOW_X(PH, "")
+#endif
+#define SNK_STEADY_SHADOW_FAR(PH) SNK_STEADY_SHADOW_XX(PH, "", SNK_STEADY_STORES_FAR)
 // (instantiations for sequences with exceptions: the candidate's mask window, same offset in the mask arena)
 #define SNK_STEADY_MASKLOAD "global_load_dwordx2 v[118:119], v104, %[marena]\n\t"
-#define SNK_STEADY_SHADOW_X(PH, LOAD2) \
+#define SNK_STEADY_SHADOW_X(PH, LOAD2) SNK_STEADY_SHADOW_XX(PH, LOAD2, "")
+#define SNK_STEADY_SHADOW_XX(PH, LOAD2, STORES) \
     "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" LOAD2 \
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
-    "global_load_dword v108, %[nxoff], %[arena]\n\t" SNK_PADC \
+    "global_load_dword v108, %[nxoff], %[arena]\n\t" STORES SNK_PADC \
     "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t" \
     "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm]\n\t" \
     "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t" \
@@ -575,13 +643,19 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "s_and_b64 %[ss], vcc, %[sv]\n\t" \
     "v_cndmask_b32_e64 v105, %[limc], 0, %[ss]\n\t"
 // compare, next cursor, next window + LUT reads, accounting, exit test (LIM = limit register)
+#ifdef SNK_PAD_LOAD
+#define SNK_STEADY_REST(LIM) SNK_STEADY_REST_XX(LIM, "", SNK_STR(SNK_PAD_LOAD_P1), SNK_STR(SNK_PAD_LOAD))   /* window: 1 + k behind it; refill: k */
+#else
 #define SNK_STEADY_REST(LIM) SNK_STEADY_REST_X(LIM, "")
+#endif
+#define SNK_STEADY_REST_FAR(LIM) SNK_STEADY_REST_XX(LIM, "", SNK_FAR_W1, SNK_FAR_W0)
 // (exceptions: the mask window ORed into the difference -- an exception in the candidate window ends the match there)
 #define SNK_STEADY_MASKOR \
     "v_alignbit_b32 v119, v119, v118, v109\n\t" \
     "v_or_b32_e32 v113, v113, v119\n\t"
-#define SNK_STEADY_REST_X(LIM, MASKOR) \
-    "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
+#define SNK_STEADY_REST_X(LIM, MASKOR) SNK_STEADY_REST_XX(LIM, MASKOR, "1", "0")
+#define SNK_STEADY_REST_XX(LIM, MASKOR, W1, W0) \
+    "s_waitcnt vmcnt(" W1 ")\n\t" SNK_PADD \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
     "v_xor_b32_e32 v113, v113, %[wc]\n\t" MASKOR \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
@@ -595,7 +669,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t" \
     "v_lshlrev_b32_e32 v116, 1, v116\n\t" \
     "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t" \
-    "s_waitcnt vmcnt(0)\n\t" \
+    "s_waitcnt vmcnt(" W0 ")\n\t" \
     "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t" \
     "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t" \
     "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t" \
@@ -617,14 +691,16 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "s_or_b64 vcc, vcc, %[st]\n\t" \
     "s_cbranch_vccz 1b\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t"
-#define SNK_STEADY_OPERANDS \
+#define SNK_STEADY_OPERANDS SNK_STEADY_OPERANDS_X()
+#define SNK_STEADY_OPERANDS_FAR SNK_STEADY_OPERANDS_X(, [gtb] "v"(gtb), [ftab] "s"(ftab), [vbm2] "v"(vb - 2u), [k17] "s"(131071))
+#define SNK_STEADY_OPERANDS_X(...) \
     : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
       [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
       [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), \
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st) \
     : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
       [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
-      [arena] "s"(arena), [marena] "s"(marena) \
+      [arena] "s"(arena), [marena] "s"(marena) __VA_ARGS__ \
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
@@ -666,8 +742,9 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 //
 // ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
-template <bool ASM, bool EXC>
+template <bool ASM, bool EXC, bool FAR>
 __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, snk_g8 *const marena, uint16_t *tbl, uint32_t *bm,
+                                                uint32_t *gt, SNK_AS1 uint32_t *const ftab, uint32_t gtb,
                                                 const uint16_t *slot, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
 {
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
@@ -726,7 +803,14 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         const uint32_t oz = (uint32_t)(olimZ - 14), dm = SNK_FSLOTS - 1u;
         // every lane's block wholly > 64 KiB past its seam (no t can land in x or on the seam)?
-        if (!EXC || !need_mask) {
+        if (FAR) {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_STEADY_TABLE_FAR SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW_FAR("%[t]") SNK_STEADY_REST_FAR("%[limc]")
+                             SNK_STEADY_OPERANDS_FAR);
+            else
+                asm volatile(SNK_STEADY_TABLE_FAR SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW_FAR("v103") SNK_STEADY_STRADDLE SNK_STEADY_REST_FAR("v105")
+                             SNK_STEADY_OPERANDS_FAR);
+        } else if (!EXC || !need_mask) {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
                              SNK_STEADY_OPERANDS);
@@ -747,14 +831,21 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #endif
     for (;;) {
         // ---- table: read slot(cur) + its bitmap word (the OR returns the old word), owed put, put(cur) ----
-        const uint32_t bit1 = s1 & 31u;
-        const uint32_t e = tbl[s1];
-        const uint32_t bw = atomicOr(&bm[s1 >> 5], 1u << bit1);
-        tbl[s2] = (uint16_t)(c - 2u);
-        atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
-        tbl[s1] = (uint16_t)c;
-        t = e + (((bw >> bit1) & 1u) << 16);
-        t = (s2 == s1) ? 65534u + c : t;                          // the owed put went to the same slot: candidate cur-2
+        if (FAR) {                                                // absolute positions in global memory, liblz4's order
+            gt[s2] = vb + c - 2u;
+            const int32_t ts = (int32_t)(gt[s1] - (uint32_t)T0);
+            gt[s1] = vb + c;
+            t = ts < 0 ? 0u : (ts > 131071 ? 131071u : (uint32_t)ts);
+        } else {
+            const uint32_t bit1 = s1 & 31u;
+            const uint32_t e = tbl[s1];
+            const uint32_t bw = atomicOr(&bm[s1 >> 5], 1u << bit1);
+            tbl[s2] = (uint16_t)(c - 2u);
+            atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+            tbl[s1] = (uint16_t)c;
+            t = e + (((bw >> bit1) & 1u) << 16);
+            t = (s2 == s1) ? 65534u + c : t;                      // the owed put went to the same slot: candidate cur-2
+        }
         valid = t > c;                                            // this block: t >= 65536 > c; previous block: e > c
 
         // ---- candidate window (global, L1) and the reservoir refill, in flight together ----
@@ -866,19 +957,26 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 //   jobs != NULL : explicit list (mixed tiles, pair lists, the single-sequence pass).
 //   jobs == NULL : dense tile of the N x N matrix: job q is the pair (x = r0 + q % rows, y = q / rows),
 //                  its size goes to out[(x - r0) * n + y].  Suffix-major, so consecutive jobs share y.
-// Work is handed out per WAVE in batches of `batch` consecutive jobs (= the lanes of a wave): wave w of
-// the launch starts with batch w; its later batches are w + k * (waves of the launch) when `queue` is
-// NULL (uniform lengths: the waves of a workgroup keep walking the same suffix y, the L1 stays hot), or
-// come from the atomic counter *queue (ragged lengths: no wave idles while jobs are left).  Inside a
-// wave a lane that finishes its pair takes the next job of the wave's batch at once.
+// Work is handed out per WAVE in batches of `batch` consecutive jobs (= the lanes of a wave).  `queue` NULL (uniform
+// lengths): wave w of the launch starts with batch w, its later batches are w + k * (waves of the launch) -- the waves
+// of a workgroup keep walking the same suffix y, the L1 stays hot.  `queue` set (ragged lengths, far chains): *queue
+// counts the JOBS handed out (starts at 0); a wave adds the number of its chains and takes that many consecutive jobs,
+// so no wave idles while jobs are left.  Inside a wave a lane that finishes its pair takes the next job of the wave's
+// batch at once.
 struct SnkFastGrid {
     const SnkJob *jobs;
     uint32_t n_jobs;
     uint32_t r0, rows, n;
     uint32_t batch;
-    uint32_t *queue;          // starts at (waves of the launch); NULL = static round robin
+    uint32_t *queue;          // jobs handed out so far (starts at 0); NULL = static round robin
     const uint32_t *yorder;   // dense tile: column visited k-th (longest suffix first when lengths are ragged: the
                               // big jobs go out first and the launch ends on small ones); NULL = column k
+    // ---- chains beyond the LDS (see snk_fast_kernel_body): waves [lds_waves, blockDim.x / 64) of a workgroup keep their
+    // chains' tables in global memory.  far_lanes = 0: none (every wave is an LDS wave).
+    uint32_t *far_tab = nullptr;   // [workgroups][far waves][far_lanes][SNK_FSLOTS] u32 absolute positions
+    uint32_t lds_waves = 0, far_lanes = 0;
+    uint32_t far_stop = 0;    // a far wave takes no further jobs once fewer than this many are left in the queue (the
+                              // LDS waves finish them sooner than a far chain would)
 };
 
 __device__ __forceinline__ SnkJob snk_fast_job(const SnkFastGrid &G, uint32_t q)
@@ -918,9 +1016,16 @@ __device__ __forceinline__ void snk_fast_lane_init(SnkFastLane &L, const SnkTabl
 // Every wave runs ONE flat loop: hand jobs to lanes that have none, general probes until every
 // working lane is eligible, steady loop until some lane needs service.  The wave leaves when its
 // lanes are idle and no job is left.
-template <bool ASM, bool EXC>
-__device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkFastGrid &G,
-                                                     uint32_t lanes, uint32_t *out, uint32_t *status)
+//
+// Chains beyond the LDS (FAR).  The LDS holds 84 chains per CU and a lone wave per SIMD leaves the SIMD's issue slots
+// half empty (a wave issues a VALU instruction every ~4 cycles, the SIMD could take one every 2), so a workgroup may
+// carry extra waves whose chains keep their tables in GLOBAL memory, sized to stay resident in the XCD's L2
+// (SnkFastGrid::far_*): u32 absolute positions, 3584 B per chain, one dependent load and two fire-and-forget stores per
+// probe.  Same probe semantics, same job stream (dynamic queue), same code around the loop; the LDS waves are untouched.
+// Not for sequences with exceptions, not for the singles pass (EXC / snapshot dumps know the LDS layout only).
+template <bool ASM, bool EXC, bool FAR>
+__device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastGrid &G,
+                                              uint32_t lanes, uint32_t *out, uint32_t *status)
 {
 #ifndef SNK_HOST_EMU
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
@@ -929,20 +1034,20 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t waves = blockDim.x >> 6;
 
-    for (uint32_t t = tid; t < 512u; t += SNK_COOP(blockDim.x))
-        ((uint32_t *)slot)[t] = ((const uint32_t *)T.lut_slot)[t];
-    __syncthreads();
-
 #ifdef SNK_STATS
     const unsigned long long stat_w0 = clock64();
-    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u };        // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
+    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
     const bool lane_on = lane < lanes;
-    const uint32_t mine_off = SNK_FLUT_B + (wave * lanes + (lane_on ? lane : 0u)) * SNK_FCHAIN_B;   // LDS address: dynamic LDS starts at 0
+    // LDS waves: the chain's table at LDS address mine_off (dynamic LDS starts at 0).  FAR waves: at word far_idx * 896 of G.far_tab.
+    const uint32_t mine_off = FAR ? 0u : SNK_FLUT_B + (wave * lanes + (lane_on ? lane : 0u)) * SNK_FCHAIN_B;
     uint8_t *const mine = snk_lds8 + mine_off;
     uint16_t *const tbl = (uint16_t *)mine;
     uint32_t *const bm = (uint32_t *)(mine + SNK_FSLOTS * 2u);
+    const uint32_t far_wave0 = FAR ? (blockIdx.x * (waves - G.lds_waves) + (wave - G.lds_waves)) * lanes : 0u;    // first chain of this wave
+    uint32_t *const gt = FAR ? G.far_tab + (size_t)(far_wave0 + (lane_on ? lane : 0u)) * SNK_FSLOTS : nullptr;
+    const uint32_t gtb = FAR ? (far_wave0 + (lane_on ? lane : 0u)) * (SNK_FSLOTS * 4u) : 0u;                   // ... as a byte offset
 
     const uint32_t n_batches = (G.n_jobs + G.batch - 1u) / G.batch;
     const uint32_t wid = blockIdx.x * waves + wave, wtotal = gridDim.x * waves;
@@ -965,18 +1070,22 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         bool need = lane_on && !have;
         while (!dry && __any(need)) {
             if (wb >= we) {
-                if (first) {
-                    first = false;
-                } else if (G.queue) {
-                    uint32_t b = 0u;
-                    if (lane == 0u) b = atomicAdd(G.queue, 1u);
-                    bcur = (uint32_t)__shfl((int)b, 0);
+                if (G.queue) {           // dynamic: the next jobs of the launch, as many as the wave has chains
+                    const uint32_t want = FAR ? lanes : G.batch;
+                    uint32_t b = 0xFFFFFFFFu;
+                    // (FAR) near the end of the launch the LDS waves finish what is left sooner than a far chain would
+                    if (lane == 0u && !(FAR && G.far_stop && *(volatile uint32_t *)G.queue + G.far_stop >= G.n_jobs))
+                        b = atomicAdd(G.queue, want);
+                    wb = (uint32_t)__shfl((int)b, 0);
+                    if (wb >= G.n_jobs) { dry = true; break; }
+                    we = wb + want < G.n_jobs ? wb + want : G.n_jobs;
                 } else {
-                    bcur += wtotal;
+                    if (first) first = false;
+                    else bcur += wtotal;
+                    if (bcur >= n_batches) { dry = true; break; }
+                    wb = bcur * G.batch;
+                    we = wb + G.batch < G.n_jobs ? wb + G.batch : G.n_jobs;
                 }
-                if (bcur >= n_batches) { dry = true; break; }
-                wb = bcur * G.batch;
-                we = wb + G.batch < G.n_jobs ? wb + G.batch : G.n_jobs;
             }
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
             const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
@@ -996,6 +1105,14 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
                 // offsets from the virtual base of the block before spos (k3 = -lx mod 4, see snk_fast_steady)
                 const uint32_t k3 = (0u - T.len[xi]) & 3u;
                 const uint32_t pvb = spos - 65536u - k3;
+                if (FAR) {        // absolute positions; 0 = stream start (no snapshot) or dead (with one: spos >= 65536 is past it)
+                    uint32_t *gdst = G.far_tab + (size_t)(far_wave0 + l) * SNK_FSLOTS;
+                    for (uint32_t t = lane; t < SNK_FSLOTS; t += SNK_COOP(64u)) {
+                        const uint32_t a0 = use ? src[t] : 0u;
+                        gdst[t] = (a0 != 0u && a0 + 65536u >= spos) ? a0 : 0u;
+                    }
+                    continue;
+                }
                 for (uint32_t t = lane; t < SNK_FSLOTS / 2u; t += SNK_COOP(64u)) {
                     uint32_t v = k3 * 0x10001u;                       // stream start: every slot holds position 0
                     if (use) {
@@ -1037,10 +1154,12 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         if (!__any(have)) {
 #ifdef SNK_STATS
             if (lane == 0u) {
-                atomicAdd(&snk_stats[7], clock64() - stat_w0);
-                atomicAdd(&snk_stats[13], P.loop); atomicAdd(&snk_stats[14], (unsigned long long)P.entries);
-                atomicAdd(&snk_stats[24], P.finish); atomicAdd(&snk_stats[25], P.rounds_cyc); atomicAdd(&snk_stats[26], (unsigned long long)P.rounds);
-                atomicAdd(&snk_stats[27], P.prologue); atomicAdd(&snk_stats[28], P.probe); atomicAdd(&snk_stats[29], P.top);
+                unsigned long long *S = snk_stats + (FAR ? 32 : 0);
+                atomicAdd(&S[7], clock64() - stat_w0);
+                atomicAdd(&S[13], P.loop); atomicAdd(&S[14], (unsigned long long)P.entries);
+                atomicAdd(&S[24], P.finish); atomicAdd(&S[25], P.rounds_cyc); atomicAdd(&S[26], (unsigned long long)P.rounds);
+                atomicAdd(&S[27], P.prologue); atomicAdd(&S[28], P.probe); atomicAdd(&S[29], P.top);
+                atomicAdd(&S[30], (unsigned long long)P.jobs); atomicAdd(&S[31], 1ull);
             }
 #endif
             return;
@@ -1107,8 +1226,11 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 #ifdef SNK_STATS
             const unsigned long long stat_g0 = clock64();
 #endif
-            if (!ok && snk_fast_iter<EXC>(L, T, tbl, bm, slot, out, status)) have = false;   // frame complete
+            bool stat_done = false;
+            if (!ok && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; }   // frame complete
+            (void)stat_done;
 #ifdef SNK_STATS
+            P.jobs += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(stat_done));
             P.probe += clock64() - stat_g0;                                                 // inside the general probes
 #endif
             if (!dry && __any(lane_on && !have)) { refill = true; break; }
@@ -1119,9 +1241,25 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
         if (have && !parked && waiting == 0u)
-            snk_fast_steady<ASM, EXC>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm, slot, mine_off,
-                                      0xFFFFFFFFu SNK_PROF_PASS);
+            snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
+                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu SNK_PROF_PASS);
     }
+}
+
+template <bool ASM, bool EXC>
+__device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const SnkFastGrid &G,
+                                                     uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+#ifndef SNK_HOST_EMU
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+#endif
+    for (uint32_t t = threadIdx.x; t < 512u; t += SNK_COOP(blockDim.x))
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    if (!EXC && G.far_lanes != 0u && (threadIdx.x >> 6) >= G.lds_waves)
+        snk_fast_wave<ASM, false, true>(T, G, G.far_lanes, out, status);
+    else
+        snk_fast_wave<ASM, EXC, false>(T, G, lanes, out, status);
 }
 
 #ifndef SNK_HOST_EMU

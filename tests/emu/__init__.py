@@ -21,11 +21,12 @@ def build():
     return _SO
 
 
-def fast_sizes(seqs, header_bytes=7, exc_limit=128, lower=False):
+def fast_sizes(seqs, header_bytes=7, exc_limit=128, lower=False, far=False):
     """(singles[n], pairs[n, n]) frame sizes the 2-bit kernel's code computes; 0 where the pair is not
     eligible for that kernel (n <= 64 KiB, or a sequence with more non-ACGT places than `exc_limit`
     16-base granules per 2^20 bases (+8) allows; exc_limit=0: pure ACGT only).  lower: the set's letters are acgt
-    (the LUTs are then made from liblz4's hashes of the lower-case 5-mers, and upper-case letters are exceptions)."""
+    (the LUTs are then made from liblz4's hashes of the lower-case 5-mers, and upper-case letters are exceptions).
+    far: the pairs run as a far chain (table in global memory; sets without exceptions only)."""
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -38,7 +39,7 @@ def fast_sizes(seqs, header_bytes=7, exc_limit=128, lower=False):
     singles = np.zeros(n, dtype=np.uint32)
     pairs = np.zeros((n, n), dtype=np.uint32)
     rc = _lib.emu_fast_sizes(n, ptrs, lens, singles.ctypes.data_as(ctypes.c_void_p),
-                             pairs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(header_bytes), ctypes.c_uint32(exc_limit), ctypes.c_uint32(1 if lower else 0))
+                             pairs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(header_bytes), ctypes.c_uint32(exc_limit), ctypes.c_uint32(1 if lower else 0), ctypes.c_uint32(1 if far else 0))
     if rc != 0:
         raise RuntimeError(f"emulated kernel reported status {rc}")
     return singles, pairs

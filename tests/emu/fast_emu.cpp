@@ -22,8 +22,10 @@ bool acgt(uint8_t c) { return c == ('A' | g_lcase) || c == ('C' | g_lcase) || c 
 
 // exc_limit: flagged 16-base granules per 2^20 bases (+8) up to which a sequence with non-ACGT bytes stays on
 // the 2-bit kernel (0: pure ACGT only).  Entries of `singles` / `pairs` that the kernel does not serve stay 0.
+// far != 0: the pairs run as a FAR chain (table in "global" memory: u32 absolute positions, snk_fast_wave<.., FAR = true>)
+// -- only for sets without exceptions (as the launch code decides).
 extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t *lens,
-                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit, uint32_t lower)
+                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit, uint32_t lower, uint32_t far)
 {
     g_lcase = lower ? 0x20 : 0;
     const char code2byte[4] = { (char)('A' | g_lcase), (char)('C' | g_lcase), (char)('T' | g_lcase), (char)('G' | g_lcase) };
@@ -136,10 +138,12 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         std::vector<uint32_t> order((size_t)n);
         for (int k = 0; k < n; ++k) order[(size_t)k] = (uint32_t)(n - 1 - k);
         G.yorder = (n & 2) ? order.data() : nullptr;
-        uint32_t counter = 1u;                           // one wave in the launch: the queue starts at 1
+        uint32_t counter = 0u;                           // the queue counts the jobs handed out
         G.queue = (n & 1) ? &counter : nullptr;          // both schedules get exercised
         if (list.size() == (size_t)n * n) { G.jobs = nullptr; G.n_jobs = (uint32_t)(n * n); }
         else                              { G.jobs = list.data(); G.n_jobs = (uint32_t)list.size(); }
+        std::vector<uint32_t> far_tab(SNK_FSLOTS, 0xDEADBEEFu);
+        if (far && !any_exc) { G.far_tab = far_tab.data(); G.lds_waves = 0u; G.far_lanes = 1u; G.far_stop = 0u; G.queue = &counter; }
         if (any_exc) snk_fast_kernel_body<false, true>(T, G, 1u, pairs, status.data());
         else         snk_fast_kernel_body<false, false>(T, G, 1u, pairs, status.data());
     }

@@ -38,6 +38,10 @@ def check(seqs, exc_limit=128):
     es, ep = expect(seqs, exc_limit)
     assert np.array_equal(s, es), (s, es)
     assert np.array_equal(p, ep), np.argwhere(p != ep)[:8].tolist()
+    if all(_packable(x, 0) or len(x) == 0 for x in seqs):
+        # pure ACGT sets: the same pairs again as a FAR chain (table in global memory, u32 absolute positions)
+        _, pf = fast_sizes(seqs, exc_limit=exc_limit, far=True)
+        assert np.array_equal(pf, ep), ("far", np.argwhere(pf != ep)[:8].tolist())
 
 
 def test_emu_ragged_block_edges():

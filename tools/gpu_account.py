@@ -19,7 +19,7 @@ if not hasattr(lib, "snk_debug_stats"):
 
 
 def run(asm):
-    st = (ctypes.c_ulonglong * 32)()
+    st = (ctypes.c_ulonglong * 64)()
     with HipContext(0, fast_asm=asm) as ctx:
         ctx.upload(seqs)
         lib.snk_debug_stats(st)                      # (reads and clears: drop the upload's single-sequence pass)

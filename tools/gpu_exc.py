@@ -50,7 +50,7 @@ for kind in KINDS:
     from snacc_amd import hip_backend
     L_ = hip_backend.load()
     if hasattr(L_, "snk_debug_stats"):
-        st = (ctypes.c_ulonglong * 32)()
+        st = (ctypes.c_ulonglong * 64)()
         L_.snk_debug_stats(st)
         names = ["steady exits", "general probes", "sentinel reads", "flushes", "byte matches", "site arrivals", "sentinel puts", "ovf-only puts"]
         print("   stats (upload + 4 launches):", {nm: int(st[i]) for i, nm in enumerate(names) if i != 7})
