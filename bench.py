@@ -38,11 +38,12 @@ sys.path.insert(0, ROOT)
 LCG_A = 6364136223846793005
 LCG_C = 1442695040888963407
 
-# Model of the bound that actually limits the 2-bit kernel: one probe per trip of the
-# steady loop for each of the chains resident on a CU; a trip cannot be shorter than the dependent chain of a
-# probe: 33 instructions on the chain at 4.2 cycles (one wave per SIMD) + table read + candidate window + slot LUT.
-LAT_MODEL = {"chain_instructions": 33, "cycles_per_instruction": 4.2, "lds_table_cycles": 60, "l1_window_cycles": 180,
-             "lds_lut_cycles": 64, "chains_per_cu": 84, "cus": 256, "clock_hz": 2.4e9}
+# What actually limits the 2-bit kernel: one probe per trip of the steady loop for each of the 84
+# chains the LDS of a CU holds, and a lone wave per SIMD issues one instruction per ~4.2 cycles (tools/gpu_lat.hip).
+# The issue-slot floor of a trip = (instructions per wave-trip, from the committed SQ counters of this kernel) x 4.2; what
+# the measured trip has on top of it is exposed waiting (L1 window, LDS / VMEM issue stalls).
+ISSUE_MODEL = {"cycles_per_issue_slot": 4.2, "waitcnt_and_branch_slots_per_trip": 6, "chains_per_cu": 84, "cus": 256, "clock_hz": 2.4e9}
+PROFILE_ROUNDS = ("r03", "r02")          # newest committed summary first
 
 
 def lcg_genomes_torch(n_genomes, length, seed0, device):
@@ -61,18 +62,28 @@ def lcg_genomes_torch(n_genomes, length, seed0, device):
     return out
 
 
-def pmc_traffic(rows, n, length, codec="lz4"):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of THIS round's kernel
-    (profiles/r02_pmc_traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE
+def _profile(stem):
+    """(parsed JSON, "profiles/<file>") of the newest committed summary `<round>_<stem>.json`, or (None, None)."""
+    for rnd in PROFILE_ROUNDS:
+        name = f"{rnd}_{stem}.json"
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f), f"profiles/{name}"
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def pmc_traffic(rows, n, length, codec="lz4", data="lcg"):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of the kernel
+    (profiles/rNN_pmc_traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE
     doubled per the gfx950 calibration of MI355X_MICROARCH.md; the file names the commit it was taken at).
-    Only valid for the launch shape it was collected on; None otherwise."""
-    name = "r02_pmc_traffic.json" if codec == "lz4" else f"r02_pmc_traffic_{codec}.json"
+    Only valid for the launch shape and data set it was collected on; None otherwise."""
+    t, src = _profile("pmc_traffic" if codec == "lz4" else f"pmc_traffic_{codec}")
     try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            t = json.load(f)
-        if (t["rows"], t["genomes"], t["length"]) == (rows, n, length):
-            return t["hbm_bytes_per_launch"], f"profiles/{name} @ {t.get('collected_at_commit', '?')}"
-    except (OSError, KeyError, ValueError):
+        if t and (t["rows"], t["genomes"], t["length"]) == (rows, n, length) and t.get("data", "lcg") == data:
+            return t["hbm_bytes_per_launch"], f"{src} @ {t.get('collected_at_commit', '?')}"
+    except KeyError:
         pass
     return None, None
 
@@ -80,15 +91,123 @@ def pmc_traffic(rows, n, length, codec="lz4"):
 def cycle_account():
     """Where the waves of the 2-bit kernel spend their cycles (stats build, tools/gpu_account.py), from the committed summary:
     the bound that limits the kernel is instruction issue and dependent latency inside its probe loop, not HBM."""
-    name = "r02_cycle_account.json"
+    a, src = _profile("cycle_account")
     try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            a = json.load(f)
         return {"cycles_per_trip_in_loop": a["cycles_per_trip_in_loop"], "trips_per_loop_entry": a["trips_per_entry"],
                 "share_outside_loop": a["share_outside_loop"], "cycles_per_exit_outside_loop": a["cycles_per_exit_outside_loop"],
-                "source": f"profiles/{name} (diagnostic build with the account kept in registers, 256 x 1 Mbp)"}
-    except (OSError, KeyError, ValueError):
+                "source": f"{src} @ {a.get('collected_at_commit', '?')} (diagnostic build with the account kept in registers, "
+                          f"{a['genomes']} x {a['length']} bp: a replay, not a measurement of this run)"}
+    except (TypeError, KeyError):
         return None
+
+
+def issue_model():
+    """Issue slots of one wave-trip of the 2-bit kernel's steady loop from the committed SQ counters (tools/gpu_pmc.sh):
+    VALU + SALU + LDS + VMEM instructions per wave-trip, plus the loop's s_waitcnt / branch slots."""
+    q, src = _profile("pmc_sq")
+    try:
+        d = q["derived_per_wave_trip"]
+        slots = d["valu"] + d["salu"] + d["lds"] + d["vmem"] + ISSUE_MODEL["waitcnt_and_branch_slots_per_trip"]
+        return {"issue_slots_per_trip": slots, "measured_cycles_per_trip": d["cycles"], "source": f"{src} @ {q.get('collected_at_commit', '?')}"}
+    except (TypeError, KeyError):
+        return None
+
+
+def lcg_related_torch(n_genomes, length, device, ancestors=16):
+    """Secondary data set of SURVEY.md 8d: genomes = 2 % point mutants of 16 LCG ancestors (ancestor a = LCG seed 1 + a;
+    genome g >= 16 = ancestor g % 16 mutated with the LCG of seed 1000 + g over the positions: substitute where
+    (s >> 40) % 50 == 0 by "ACGT"[(s >> 33) & 3], the mutant rule of SURVEY.md 8c)."""
+    import torch
+    a = torch.full((length,), LCG_A, dtype=torch.int64, device=device)
+    apow = torch.cumprod(a, 0)
+    geo = torch.cumsum(torch.cat([torch.ones(1, dtype=torch.int64, device=device), apow[:-1]]), 0)
+    cg = geo * LCG_C
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    anc = [lut[(((apow * (1 + k) + cg) >> 33) & 3)] for k in range(ancestors)]
+    out = []
+    for g in range(n_genomes):
+        if g < ancestors:
+            out.append(anc[g].cpu().numpy())
+            continue
+        s = apow * (1000 + g) + cg
+        hit = (((s >> 40) & 0xFFFFFF) % 50) == 0
+        out.append(torch.where(hit, lut[(s >> 33) & 3], anc[g % ancestors]).cpu().numpy())
+    return out
+
+
+def markov_genomes_torch(n_genomes, length, device, seed=20261004):
+    """Secondary data set with the statistics uniform random DNA lacks: an order-3 Markov chain over ACGT (one fixed,
+    moderately skewed transition table; 16 independently started segments per genome so that the chain runs as a wide
+    vector), then tandem repeats (unit 1 .. 60 bases x 3 .. 40 copies, one per ~25 kbp) and a few point mutations inside
+    them -- the low-complexity runs and long matches that drive the 2-bit kernel's rare paths."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    cum = torch.tensor(np.cumsum(rng.dirichlet([2.0] * 4, size=64), axis=1)[:, :3], dtype=torch.float32, device=device)
+    seg = 16
+    steps = (length + seg - 1) // seg
+    lanes = n_genomes * seg
+    state = torch.randint(0, 64, (lanes,), generator=g, device=device)
+    out = torch.empty((steps, lanes), dtype=torch.uint8, device=device)
+    block = 2048
+    for t0 in range(0, steps, block):
+        u = torch.rand((min(block, steps - t0), lanes), generator=g, device=device)
+        for k in range(u.shape[0]):
+            nxt = (u[k].unsqueeze(1) > cum[state]).sum(1)
+            out[t0 + k] = nxt.to(torch.uint8)
+            state = ((state << 2) | nxt) & 63
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    seqs = lut[out.long()].view(steps, n_genomes, seg).permute(1, 2, 0).reshape(n_genomes, seg * steps)[:, :length].cpu().numpy()
+    res = []
+    for i in range(n_genomes):
+        s = seqs[i].copy()
+        for _ in range(max(1, length // 25000)):
+            unit, copies = int(rng.integers(1, 61)), int(rng.integers(3, 41))
+            p = int(rng.integers(0, max(1, length - unit * copies - 1)))
+            n = min(unit * copies, length - p)
+            s[p:p + n] = np.tile(s[p:p + unit], copies)[:n]
+            if n > 40:
+                s[p + int(rng.integers(0, n))] = b"ACGT"[int(rng.integers(0, 4))]
+        res.append(s)
+    return res
+
+
+def write_fasta_files(directory, genomes, width=80):
+    """One single-record FASTA file per genome, 80-column lines, without a Python loop per line."""
+    os.makedirs(directory, exist_ok=True)
+    for i, a in enumerate(genomes):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        full = len(a) // width * width
+        with open(os.path.join(directory, f"g{i:05d}.fasta"), "wb") as f:
+            f.write(b">g%05d synthetic\n" % i)
+            body = np.empty((full // width, width + 1), dtype=np.uint8)
+            body[:, :width] = a[:full].reshape(-1, width)
+            body[:, width] = 10
+            f.write(body.tobytes())
+            if full < len(a):
+                f.write(a[full:].tobytes() + b"\n")
+
+
+def cli_wall(genomes, codec, tmp_root):
+    """End to end through the drop-in CLI: `snacc <dir of N FASTA files> -c <codec> -o out.csv` (FASTA ingest by the
+    library's host threads, upload, singles, all N x N pairs, NCD, CSV).  The files are written before the clock starts."""
+    import shutil
+    from snacc_amd.cli import cli
+    d = os.path.join(tmp_root, f"snacc_bench_fa_{os.getpid()}")
+    try:
+        write_fasta_files(d, genomes)
+        out = os.path.join(d, "out.csv")
+        import contextlib
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):          # the CLI's banners: stdout carries the ONE JSON line only
+            cli.main(args=[d, "-o", out, "-c", codec, "--no-show-progress", "--no-log"], standalone_mode=False)
+        wall = time.perf_counter() - t0
+        ok = os.path.getsize(out) > 0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return {"cli_wall_s": wall, "files": len(genomes), "csv_written": ok,
+            "what": f"snacc <{len(genomes)} FASTA files> -c {codec} -o out.csv --no-show-progress --no-log, in process; files written untimed"}
 
 
 def cgroup_cpu_quota():
@@ -230,6 +349,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true", help="skip the measured full-matrix run")
     ap.add_argument("--codec", choices=["lz4", "gzip", "zlib"], default="lz4")
+    ap.add_argument("--data", choices=["lcg", "related", "markov"], default="lcg",
+                    help="lcg (default, the metric's data set: i.i.d. uniform ACGT); related: 2 %% mutants of 16 ancestors; "
+                         "markov: order-3 Markov chain + tandem repeats (secondary data sets, SURVEY.md 8d)")
+    ap.add_argument("--no-cli-wall", action="store_true", help="skip the end-to-end CLI run (FASTA files -> CSV)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,7 +384,15 @@ def main():
     N, L, R = args.genomes, args.length, args.rows_per_step
     R = min(R, max(1, N // world))
     t0 = time.time()
-    genomes = lcg_genomes_torch(N, L, 1, dev)          # seed = 1 + genome index
+    if args.data == "lcg":
+        genomes = lcg_genomes_torch(N, L, 1, dev)      # seed = 1 + genome index
+        data_desc = "synthetic (LCG uniform ACGT, seed = 1 + genome index)"
+    elif args.data == "related":
+        genomes = lcg_related_torch(N, L, dev)
+        data_desc = "synthetic (2 % point mutants of 16 LCG ancestors; secondary data set)"
+    else:
+        genomes = markov_genomes_torch(N, L, dev)
+        data_desc = "synthetic (order-3 Markov chain + tandem repeats; secondary data set)"
     t_gen = time.time() - t0
 
     opts = {}
@@ -441,22 +572,28 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu_baseline = (cpu_baseline_deflate(genomes, L, args.codec, args.cpu_seconds) if deflate
                             else cpu_baseline_lz4(genomes, L, args.cpu_seconds))
+    cli_run = None
+    if rank == 0 and world == 1 and not args.no_cli_wall:
+        cli_run = cli_wall(genomes, args.codec, os.environ.get("TMPDIR", "/tmp"))
 
     if rank == 0:
         if args.mode == "strong" and matrix:
             pair_rate = (N * N + N) / matrix["matrix_wall_s"]
         ncd_rate = pair_rate / 2.0                        # 1 NCD = 2 ordered pair-compressions
-        traffic, traffic_src = pmc_traffic(R, N, L, args.codec)
-        latency_bound = None
-        if probes_per_pair:
-            mdl = LAT_MODEL
-            trip = (mdl["chain_instructions"] * mdl["cycles_per_instruction"] + mdl["lds_table_cycles"]
-                    + mdl["l1_window_cycles"] + mdl["lds_lut_cycles"])
-            peak = mdl["cus"] * mdl["chains_per_cu"] * mdl["clock_hz"] / trip
+        traffic, traffic_src = pmc_traffic(R, N, L, args.codec, args.data)
+        issue_bound = None
+        im = issue_model() if probes_per_pair else None
+        if im:
+            mdl = ISSUE_MODEL
+            floor = im["issue_slots_per_trip"] * mdl["cycles_per_issue_slot"]
+            peak = mdl["cus"] * mdl["chains_per_cu"] * mdl["clock_hz"] / floor
             ach = R * N * probes_per_pair / (kern_ms_avg * 1e-3)
-            latency_bound = {"bound": "dependent-probe latency x chains resident in LDS (the limiter; HBM is idle)",
-                             "achieved": ach, "peak": peak, "unit": "probes/s per GPU", "frac": ach / peak,
-                             "probes_per_pair": probes_per_pair, "model": dict(mdl, trip_cycles=trip)}
+            issue_bound = {"bound": "instruction issue of one wave per SIMD x chains resident in LDS (the limiter; HBM is idle)",
+                           "achieved": ach, "peak": peak, "unit": "probes/s per GPU", "frac": ach / peak,
+                           "probes_per_pair": probes_per_pair,
+                           "model": dict(mdl, issue_slots_per_trip=im["issue_slots_per_trip"], issue_floor_cycles_per_trip=floor,
+                                         measured_cycles_per_trip=im["measured_cycles_per_trip"],
+                                         exposed_wait_cycles_per_trip=im["measured_cycles_per_trip"] - floor, source=im["source"])}
         par = f"row-shard x{world}"
         if world > 1:
             par += " + gloo all-gather (ONE-GPU REHEARSAL, not a measurement)" if rehearse else " + RCCL all-gather (async, overlapped)"
@@ -466,20 +603,25 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic (LCG uniform ACGT, seed = 1 + genome index)",
+            "dtype": "u8", "data": data_desc,
             "config": {"workload": f"{N} synthetic {L} bp genomes, {args.codec}, rows_per_step={R} x {N} cols per GPU",
                        "genomes": N, "length": L, "rows_per_step_per_gpu": R, "parallelism": par},
             "pair_compressions_per_s": pair_rate,
             "matrix_wall_s": matrix["matrix_wall_s"] if matrix else None,
             "matrix": matrix,
             "matrix_wall_s_est": (N * N + N) / (pairs_per_step * args.steps / elapsed),
+            # achieved / frac: ALGORITHMIC bytes per launch over the launch time; traffic: HBM bytes the
+            # counters saw; hbm_gbps / hbm_frac: that traffic over the same time -- what HBM itself is asked for
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "hbm_gbps": (traffic / (kern_ms_avg * 1e-3) / 1e9) if traffic else None,
+                         "hbm_frac": (traffic / (kern_ms_avg * 1e-3) / 1e9 / 8000.0) if traffic else None,
                          "kernel": "dfl_parse_kernel" if deflate else ("snk_fast_kernel" if not args.force_generic else "snk_bytes_compact_kernel"),
                          "kernel_ms_avg": kern_ms_avg, "kernel_launches_averaged": len(kern_ms),
                          "kernel_ms_region_torch_events": kern_ms_region,
                          "alg_bytes_per_launch": alg_bytes_launch},
-            "latency_bound": latency_bound,
+            "issue_bound": issue_bound,
+            "cli_wall_s": cli_run["cli_wall_s"] if cli_run else None, "cli": cli_run,
             "cycle_account": cycle_account() if args.codec == "lz4" else None,
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": parity, "allgather_check": gather_ok,

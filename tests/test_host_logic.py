@@ -237,7 +237,8 @@ def test_single_item_gzip_needs_the_hip_backend_by_default(sample_fa, monkeypatc
 
 def test_bench_reads_the_committed_profile_summaries():
     """bench.py quotes HBM traffic and the wave cycle account from the round's committed rocprofv3 / stats summaries
-    (profiles/r02_*.json): the files parse, name their source, and match the launch shape the bench line is quoted on."""
+    (profiles/rNN_*.json, newest round first): the files parse, name their source and the commit they were taken at, and match
+    the launch shape the bench line is quoted on."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -246,7 +247,12 @@ def test_bench_reads_the_committed_profile_summaries():
     spec.loader.exec_module(bench)
     for codec in ("lz4", "gzip", "zlib"):
         traffic, src = bench.pmc_traffic(84, 1024, 1000000, codec)
-        assert traffic and traffic > 0 and src.startswith("profiles/r02_pmc_traffic"), (codec, traffic, src)
+        assert traffic and traffic > 0 and src.startswith("profiles/r0") and "pmc_traffic" in src, (codec, traffic, src)
+    assert bench.pmc_traffic(84, 1024, 1000000, "lz4")[1].startswith("profiles/r03_pmc_traffic.json @ ")
+    assert "?" not in bench.pmc_traffic(84, 1024, 1000000, "lz4")[1]                  # names its commit
     assert bench.pmc_traffic(84, 1000, 1000000)[0] is None           # another launch shape: no figure
+    assert bench.pmc_traffic(84, 1024, 1000000, "lz4", "markov")[0] is None   # another data set: no figure
+    im = bench.issue_model()
+    assert 60 < im["issue_slots_per_trip"] < 100 and im["measured_cycles_per_trip"] > im["issue_slots_per_trip"] * 4
     acc = bench.cycle_account()
     assert 300 < acc["cycles_per_trip_in_loop"] < 800 and 0 < acc["share_outside_loop"] < 0.5 and "profiles/" in acc["source"]

@@ -42,4 +42,5 @@ out = {"genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
        "per_exit": {"finish": a[24] / entries, "general_rounds_and_reseat": a[25] / entries, "rounds": a[26] / entries, "prologue": a[27] / entries},
        "service_requests_per_pair": {k: c[i] / pairs for i, k in [(16, "literal run >= 15"), (17, "back-extension 4"), (18, "output budget"),
                                                                   (19, "12 equal bases"), (20, "block end"), (21, "other limit"), (22, "seam straddle")]}}
+out["collected_at_commit"] = sys.argv[3] if len(sys.argv) > 3 else "?"
 print(json.dumps(out, indent=1))

@@ -5,7 +5,7 @@
 OUT=${1:?usage: gpu_pmc_dfl.sh OUT.json COMMIT [gzip|zlib]}; COMMIT=${2:?COMMIT (tools/commit_id.sh) is required}; CODEC=${3:-gzip}
 export TMPDIR=/tmp
 D=$(dirname "$OUT")/pmcd_raw; mkdir -p "$D"
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$D/raw" -- python3 bench.py --codec $CODEC --steps 1 --warmup 0 --no-cpu-baseline --no-matrix > "$D/run.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$D/raw" -- python3 bench.py --codec $CODEC --steps 1 --warmup 0 --no-cpu-baseline --no-matrix --no-cli-wall > "$D/run.log" 2>&1
 f=$(find "$D/raw" -name '*counter_collection.csv' | head -1)
 python3 - "$f" "$OUT" "$COMMIT" "$CODEC" <<'PY'
 import csv, sys, collections, json

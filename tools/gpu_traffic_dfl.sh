@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/pmc_traffic_gzip.json}; COMMIT=${2:?COMMIT (tools/commit_id.
 export TMPDIR=/tmp
 D=$(dirname "$OUT")/traffic_raw_dfl; mkdir -p "$D"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$D/$c" -- python3 bench.py --codec $CODEC --steps 1 --warmup 0 --no-cpu-baseline --no-matrix > "$D/$c.log" 2>&1
+  rocprofv3 --pmc $c --output-format csv -d "$D/$c" -- python3 bench.py --codec $CODEC --steps 1 --warmup 0 --no-cpu-baseline --no-matrix --no-cli-wall > "$D/$c.log" 2>&1
 done
 python3 - "$D" "$OUT" "$COMMIT" "$CODEC" <<'PY'
 import csv, glob, json, sys
