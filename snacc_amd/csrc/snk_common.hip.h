@@ -63,8 +63,8 @@ struct SnkTables {
     const uint8_t  *bytes_arena;      // the same ASCII data as one allocation < 4 GiB; starts with SNK_PAD zero bytes
     const uint32_t *bytes_off;        // byte offset of each sequence in the ASCII arena
     const uint8_t  *packed_arena;     // 2-bit packed sequences, one allocation < 4 GiB; SNK_ARENA_SLACK zero bytes in front and behind
-    const uint8_t  *mask_arena;       // same layout, 2 bits per base: 11 where the byte is not one of ACGT (NULL: no resident
-                                      // 2-bit sequence has exceptions)
+    const uint8_t  *mask_arena;       // same layout, a 2-bit class per base: 00 the set's letters, 01 the same letters in the other
+                                      // case, 11 any other byte (NULL: no resident 2-bit sequence has exceptions)
     const uint32_t *packed_off;       // byte offset of each packed sequence in the arena (0 = not packed)
     const uint32_t *len;
     const uint32_t *snap_pos;         // block-aligned prefix length covered by the snapshot (0 = none)
@@ -83,6 +83,8 @@ struct SnkTables {
     const uint32_t *exc_roff;         // per sequence: index of its first pair in exc_runs (only read when exc_off says it has some)
     const uint16_t *lut_h2s;          // [4096] liblz4 hash of 5 bytes -> slot of the 2-bit table, 0xFFFF = no ACGT 5-mer has it
     const uint16_t *lut_s2h;          // [896]  slot -> hash
+    const uint16_t *lut_okey;         // [1024] 5-mer code -> where liblz4 keeps the 5-mer written in the OTHER case: the slot of the
+                                      // 2-bit table (< 896) when a 5-mer of the set's case has the same hash, else 0x1000 | hash (ovf)
     uint32_t       *ovf;              // [resident chains][4096] overflow tables (absolute positions, liblz4's own layout)
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };

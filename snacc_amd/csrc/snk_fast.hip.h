@@ -26,6 +26,7 @@
 
 struct SnkFastSrc {
     snk_g8 *arena;            // wave-uniform base of the packed arena (SGPR base + 32-bit lane offsets)
+    snk_g8 *marena;           // ... of the class arena (sequences with exceptions; same layout)
     uint32_t xoff, yoff;      // byte offsets of the two packed sequences inside the arena
     uint32_t lx;
 };
@@ -55,6 +56,14 @@ __device__ __forceinline__ uint32_t snk_fetch32(const SnkFastSrc &s, uint32_t p)
 __device__ __forceinline__ uint32_t snk_base_at(const SnkFastSrc &s, uint32_t p)
 {
     return snk_fetch32(s, p + 4u) & 3u;
+}
+
+// The same window from the class arena (2-bit class per base: 00 the set's letters, 01 the other case, 11 another byte).
+__device__ __forceinline__ uint32_t snk_fetch32m(const SnkFastSrc &s, uint32_t p)
+{
+    SnkFastSrc m = s;
+    m.arena = s.marena;
+    return snk_fetch32(m, p);
 }
 
 // Cursor-side reservoir: 32 packed bases [rb, rb+32) of ONE source sequence in registers
@@ -106,6 +115,9 @@ struct SnkFastLane {
                                            // scan found the cursor at): no look at the run list for them
     uint32_t mask_until;                   // cursors below this may read a table entry whose window holds an exception: the
                                            // steady loop then runs with the mask window (see "Exceptions" below)
+    uint32_t olo, olim;                    // cursors in [olo, olim) have a window of other-case letters only (class 01): the
+                                           // steady loop's other-case mode serves them (see snk_exc_other_ready); olo = olim: unknown
+    uint32_t oscan;                        // cursor of the last scan that found no such range (not scanned again there)
 };
 
 // diagnostic build only (-DSNK_STATS, `make stats`): event counters of the exception machinery (tools/gpu_exc.py) and a
@@ -124,7 +136,7 @@ __device__ unsigned long long snk_stats[64];      // [32..63]: the same account 
 #endif
 // the cycle account is kept in registers and added to snk_stats once, when the wave ends (atomics on the way would
 // change what they measure): every lane carries the same numbers, lane 0 reports them
-struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top; unsigned int entries, rounds, jobs; };
+struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top, other, otrips, olanes; unsigned int entries, rounds, jobs, oruns; };
 #define SNK_PROF_ARG , SnkProf &P
 #define SNK_PROF_PASS , P
 #else
@@ -286,6 +298,135 @@ __device__ __forceinline__ void snk_exc_finish(SnkFastLane &L, uint32_t cur, uin
     }
 }
 
+#if defined(SNK_STATS) && SNK_STATS + 0 >= 3
+// diagnostic build only (STATS=3): where the general probe of a sequence with exceptions spends its cycles
+// (snk_stats[40..47], by the first active lane; tools/gpu_exc.py prints them)
+#define SNK_PSTAMP0 unsigned long long stp_ = clock64(); const bool stp_on_ = (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))
+#define SNK_PSTAMP(i) do { const unsigned long long n_ = clock64(); if (stp_on_) atomicAdd(&snk_stats[40 + (i)], n_ - stp_); stp_ = n_; } while (0)
+#else
+#define SNK_PSTAMP0 do { } while (0)
+#define SNK_PSTAMP(i) do { } while (0)
+#endif
+
+// ---- the general probe on (code, class) windows ---------------------------------------------------------------
+// A byte of a 2-bit sequence is named exactly by its 2-bit code and its class unless the class is 11 (another byte: N,
+// IUPAC codes).  So the general probe of a sequence with exceptions -- every cursor position of a soft-masked stretch --
+// can hash, look up and compare on the packed and class arenas, which the wave's neighbours keep hot in the L1, instead
+// of on the ASCII arena (cold lines, byte loops): the 5-mer's key comes from a LUT (the set's case: its slot; the other
+// case: lut_okey), the candidate is compared as two 32-bit windows.  Whenever a class-11 byte could decide (inside the
+// hashed 5 bytes, or where the match stops) the byte-accurate code above takes over, so the result is liblz4's in every case.
+struct SnkKey { uint32_t s; uint32_t h; bool ok; };   // s < 896: slot of the 2-bit table; else ovf[h]; ok: the windows decided
+
+__device__ __forceinline__ SnkKey snk_exc_key(const SnkTables &T, const uint16_t *slot, uint32_t code, uint32_t cls)
+{
+    SnkKey k; k.h = 0u; k.ok = true;
+    if (cls == 0u)          k.s = slot[code];                          // five letters of the set's case
+    else if (cls == 0x155u) {                                          // ... of the other case
+        const uint32_t v = T.lut_okey[code];
+        k.s = v < SNK_FSLOTS ? v : 0xFFFFu; k.h = v & 0xFFFu;
+    } else { k.s = 0xFFFFu; k.ok = false; }                            // mixed, or another byte: hash the real bytes
+    return k;
+}
+
+__device__ __forceinline__ void snk_exc_put_key(SnkFastLane &L, uint16_t *tbl, uint32_t *bm, const SnkKey k, uint32_t pos)
+{
+    if (k.s != 0xFFFFu) {
+        tbl[k.s] = (uint16_t)(pos - L.base);
+        atomicOr(&bm[k.s >> 5], 1u << (k.s & 31u));
+    } else {
+        L.ovf[k.h] = pos;
+    }
+}
+
+__device__ __forceinline__ uint32_t snk_exc_get_key(const SnkFastLane &L, const uint16_t *tbl, const uint32_t *bm, const SnkKey k,
+                                                    uint32_t cur, bool &valid)
+{
+    if (k.s != 0xFFFFu) {
+        const uint32_t e = tbl[k.s];
+        const bool iscur = ((bm[k.s >> 5] >> (k.s & 31u)) & 1u) != 0u;
+        valid = iscur | (e > cur - L.base);
+        return L.base + e - (iscur ? 0u : 65536u);
+    }
+    const uint32_t cand = L.ovf[k.h];
+    valid = cand + SNK_MAXDIST >= cur;
+    return cand;
+}
+
+// positions (both bits of the base's pair) whose class is 11
+__device__ __forceinline__ uint32_t snk_c11(uint32_t m)
+{
+    const uint32_t b = m & (m >> 1) & 0x55555555u;
+    return b | (b << 1);
+}
+
+// Finish the probe at `cur` (table operations done, candidate `cand`) on the windows wc / wk (codes / classes at cur).
+// Returns false when a class-11 byte could decide: the caller then finishes on the real bytes.
+__device__ __forceinline__ bool snk_exc_finish_win(SnkFastLane &L, uint32_t cur, uint32_t cand, bool valid, uint32_t wc, uint32_t wk)
+{
+    if (!valid) {
+        const uint32_t s3 = L.nb >> 6;
+        L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
+        return true;
+    }
+    const uint32_t wd = snk_fetch32(L.s, cand), wdk = snk_fetch32m(L.s, cand);
+    // diff: the bytes differ for certain (codes differ, or classes differ -- a class-11 byte is never a letter);
+    // amb: both bytes are of class 11 with equal codes (N and N, N and R, ...): only the real bytes can tell
+    const uint32_t diff = (wc ^ wd) | (wk ^ wdk), amb = snk_c11(wk) & snk_c11(wdk);
+    const uint32_t x = diff | amb;
+    const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;              // bases from cur up to the first event, 0..12
+    if (f < 12u && ((diff >> (8u + 2u * f)) & 3u) == 0u) return false;                    // the event is a pair of class-11 bytes: bytes decide
+    if (f < 4u) {                                                                         // the first four bytes differ: no match
+        const uint32_t s3 = L.nb >> 6;
+        L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
+        return true;
+    }
+    const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;  // equal bases before cur, 0..4
+    uint32_t lit = cur - L.anchor;
+    uint32_t b = eq < lit ? eq : lit;
+    b = b < cand ? b : cand;
+    if (b == eq && eq < 4u && ((diff >> (6u - 2u * eq)) & 3u) == 0u) return false;        // the back-extension stops at a pair of class-11 bytes
+    lit -= b;
+    const uint32_t e2 = cur + f, opn = L.op + lit + 3u;
+    if ((f < 12u) & (b < 4u) & (lit < 15u) & (opn + 6u <= L.olimit) & (e2 < L.mfl1)) {
+        L.op = opn; L.anchor = e2; L.cur = e2; L.step = 1u; L.nb = 63u; L.pending = true;
+    } else {
+        snk_exc_match(L, cur, cand);                                                      // may run on: liblz4's loops on the real bytes
+    }
+    return true;
+}
+
+// ---- other-case stretches (soft-masked genomes) ------------------------------------------------------------------
+// Inside a stretch of the other case every cursor window is "unclean" for the steady loop proper, but it is as regular
+// as the rest of the genome: letters only, all of one case.  Such cursors run a second mode of the steady loop (OTH, C++
+// statement only): the 5-mer's key comes from lut_okey (liblz4's hash of the other-case 5-mer: a slot of the 2-bit
+// table where a 5-mer of the set's case shares the hash, else the chain's overflow table), the candidate's class
+// window must be 01 throughout (XOR with 0x55555555 joins the difference), everything else is the loop as it is.
+// [olo, olim): cursors whose window [p-4, p+12) lies inside one sequence and holds class 01 only, found by a scan of the
+// class arena from the cursor on (up to 4096 bases at a time).
+__device__ __forceinline__ bool snk_exc_other_ready(SnkFastLane &L)
+{
+    const uint32_t cur = L.cur, lx = L.s.lx;
+    if (cur - L.olo < L.olim - L.olo) return true;
+    if (cur == L.oscan) return false;
+    L.oscan = cur; L.olo = L.olim = 0u;
+    const bool iny = cur >= lx + 4u;
+    if (!iny && !(cur >= 4u && cur + 12u <= lx)) return false;             // seam gap, stream start
+    if (snk_fetch32m(L.s, cur) != 0x55555555u) return false;
+    const uint32_t org = iny ? lx : 0u, soff = iny ? L.s.yoff : L.s.xoff;
+    uint32_t q = cur - org + 12u;                                           // first base behind the cursor's window
+    const uint32_t qend = q + 4096u;
+    uint32_t bad = 0xFFFFFFFFu;
+    while (q < qend) {
+        const uint64_t v = snk_ld8g(L.s.marena + (size_t)(soff + (q >> 2))) ^ 0x5555555555555555ull;      // 32 bases from q & ~3
+        const uint64_t m = v >> (2u * (q & 3u));                            // base q at bit 0 (behind the end: class 00 -> set)
+        if (m) { bad = q + ((uint32_t)__builtin_ctzll(m) >> 1); break; }
+        q += 32u - (q & 3u);
+    }
+    L.olo = cur;
+    L.olim = org + (bad != 0xFFFFFFFFu ? bad : q) - 11u;                    // first cursor whose window reaches the bad base
+    return L.olim > cur;
+}
+
 // Rare path (once per 64 KiB): close the finished block, age the table, open the next block.
 // Returns true when the frame is complete (size written).
 // FAR (chains of the extra waves, see "Chains beyond the LDS" below): the table is gt[896], absolute positions as u32 in
@@ -438,13 +579,34 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
         // (a cursor at L.xlim stands at a site -- the caller keeps xlim at the first position >= the cursor whose window is
         // not clean -- and needs no look at the flags)
         if (cur >= L.xlim || !snk_exc_clean(L, cur) || (L.pending && !snk_exc_clean(L, cur - 2u))) { L.mask_until = cur + 65536u; SNK_COUNT_HEAVY(6); }
-        if (L.pending) snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
-        const uint64_t wc = snk_ld8(L.g, cur);
-        const uint32_t h = snk_hash5(wc);
+        // the windows of the cursor: codes and classes of the bases [cur-4, cur+12); 5-mer at cur = bits 8..17, at cur-2 = bits 4..13
+        SNK_PSTAMP0;
+        const uint32_t wc = snk_fetch32(L.s, cur), wk = snk_fetch32m(L.s, cur);
+        SNK_PSTAMP(0);
+        if (L.pending) {
+            const SnkKey k2 = snk_exc_key(T, slot, (wc >> 4) & 1023u, (wk >> 4) & 1023u);
+            if (k2.ok) snk_exc_put_key(L, tbl, bm, k2, cur - 2u);
+            else       snk_exc_put(L, T, tbl, bm, snk_hash5(snk_ld8(L.g, cur - 2u)), cur - 2u);
+        }
+        SNK_PSTAMP(1);
+        const SnkKey k1 = snk_exc_key(T, slot, (wc >> 8) & 1023u, (wk >> 8) & 1023u);
+        if (k1.ok) {
+            bool valid;
+            SNK_PSTAMP(2);
+            const uint32_t cand = snk_exc_get_key(L, tbl, bm, k1, cur, valid);
+            snk_exc_put_key(L, tbl, bm, k1, cur);
+            SNK_PSTAMP(3);
+            if (!snk_exc_finish_win(L, cur, cand, valid, wc, wk))
+                snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
+            SNK_PSTAMP(4);
+            return false;
+        }
+        const uint64_t wb = snk_ld8(L.g, cur);
+        const uint32_t h = snk_hash5(wb);
         bool valid;
         const uint32_t cand = snk_exc_get(L, T, tbl, bm, h, cur, valid);
         snk_exc_put(L, T, tbl, bm, h, cur);
-        snk_exc_finish(L, cur, cand, valid, wc);
+        snk_exc_finish(L, cur, cand, valid, wb);
         return false;
     }
     const uint32_t wc = snk_fetch32(L.s, cur);
@@ -742,11 +904,14 @@ __device__ __forceinline__ bool snk_fast_eligible(const SnkFastLane &L)
 //
 // ASM = true: the loop proper is the hand-scheduled gfx950 code below (same dataflow, statement for
 // statement); ASM = false: the C++ statement of it, which is also what the CPU emulation runs.
-template <bool ASM, bool EXC, bool FAR>
+// OTH (with EXC, C++ statement only): the other-case mode, see snk_exc_other_ready; okey = lut_okey.
+template <bool ASM, bool EXC, bool FAR, bool OTH = false>
 __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const arena, snk_g8 *const marena, uint16_t *tbl, uint32_t *bm,
                                                 uint32_t *gt, SNK_AS1 uint32_t *const ftab, uint32_t gtb,
-                                                const uint16_t *slot, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
+                                                const uint16_t *slot, uint32_t lds_off, uint32_t round_bases,
+                                                const uint16_t *okey SNK_PROF_ARG)
 {
+    static_assert(!OTH || (EXC && !ASM && !FAR), "the other-case mode exists as the C++ statement of the loop for sequences with exceptions");
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
 #ifdef SNK_STATS
     const unsigned long long stat_te = clock64();
@@ -767,11 +932,12 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     const int32_t sx = (int32_t)L.s.lx - 11 - T0;                 // t < sx: window inside x; t >= sx + 15: inside y
     const uint32_t limw = w.lim == 0xFFFFFFFFu ? w.lim : w.lim + 1u;
     uint32_t lim_abs = L.mfl1 < limw ? L.mfl1 : limw;
-    if (EXC) lim_abs = lim_abs < L.xlim ? lim_abs : L.xlim;       // ... the cursor window must stay clean
+    if (EXC) { const uint32_t xl = OTH ? L.olim : L.xlim; lim_abs = lim_abs < xl ? lim_abs : xl; }   // ... the cursor window must stay clean (OTH: of class 01)
     if (EXC && round_bases != 0xFFFFFFFFu && lim_abs - L.cur > round_bases) lim_abs = L.cur + round_bases;   // a short round
     const uint32_t limc = lim_abs - vb;                           // next probe position >= limc: service
     // (EXC, wave-uniform) can a lane of this run read an entry whose window holds an exception?  Only then the mask window is loaded.
-    const bool need_mask = EXC && __any(L.cur < L.mask_until);
+    const bool need_mask = OTH || (EXC && __any(L.cur < L.mask_until));
+    const uint32_t kcls = OTH ? 0x55555555u : 0u;                 // the class every base of the candidate must have
     const int32_t olimZ = (int32_t)L.olimit - (int32_t)SNK_FAST_ZONE + 10;      // olimit - 70: eligibility needs op <= olimit - 80
 
     uint32_t c = L.cur - vb, anchor_c = L.anchor - vb, op = L.op;
@@ -785,11 +951,17 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         r0 = sl ? r1 : r0; r1 = sl ? r2 : r1;
         rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
         wc = __builtin_amdgcn_alignbit(r1, r0, 2u * no);
-        s1 = lut0[(wc >> 8) & 1023u];
-        s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
+        if (OTH) {
+            s1 = okey[(wc >> 8) & 1023u];
+            s2 = L.pending ? (uint32_t)okey[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);
+        } else {
+            s1 = lut0[(wc >> 8) & 1023u];
+            s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
+        }
     }
     uint32_t t; bool valid;
 #ifdef SNK_STATS
+    unsigned int stat_otrips = 0u;
     const unsigned long long stat_t0 = clock64();
     P.prologue += stat_t0 - stat_te;
 #endif
@@ -831,7 +1003,26 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #endif
     for (;;) {
         // ---- table: read slot(cur) + its bitmap word (the OR returns the old word), owed put, put(cur) ----
-        if (FAR) {                                                // absolute positions in global memory, liblz4's order
+#ifdef SNK_HOST_EMU
+        if (OTH) snk_emu_oth_trips++;
+#endif
+#ifdef SNK_STATS
+        if (OTH) stat_otrips++;
+#endif
+        if (OTH) {      // keys: < 896 a slot of the 2-bit table (u16 + bitmap), else 0x1000 | hash: the overflow table (absolute)
+            if (s2 < SNK_FSLOTS) { tbl[s2] = (uint16_t)(c - 2u); atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u)); }
+            else                 L.ovf[s2 & 0xFFFu] = vb + c - 2u;
+            if (s1 < SNK_FSLOTS) {
+                const uint32_t e = tbl[s1];
+                const uint32_t bw = atomicOr(&bm[s1 >> 5], 1u << (s1 & 31u));
+                tbl[s1] = (uint16_t)c;
+                t = e + (((bw >> (s1 & 31u)) & 1u) << 16);
+            } else {
+                const int32_t ts = (int32_t)(L.ovf[s1 & 0xFFFu] - (uint32_t)T0);
+                L.ovf[s1 & 0xFFFu] = vb + c;
+                t = ts < 0 ? 0u : (ts > 131071 ? 131071u : (uint32_t)ts);
+            }
+        } else if (FAR) {                                         // absolute positions in global memory, liblz4's order
             gt[s2] = vb + c - 2u;
             const int32_t ts = (int32_t)(gt[s1] - (uint32_t)T0);
             gt[s1] = vb + c;
@@ -863,7 +1054,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         }
 
         // ---- compare, next cursor ----
-        const uint32_t x = (wc ^ wd) | wm;
+        const uint32_t x = (wc ^ wd) | (wm ^ kcls);
         const uint32_t r = snk_ffbl(x >> 8);                      // 2 * equal bases from cur; 0xFFFFFFFF: all 12
         const bool m = valid & (r >= 8u);
         const uint32_t e2 = c + (r >> 1);                         // all 12 equal: huge; past the match limit: >= limc -> service
@@ -874,8 +1065,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         const bool sl = no >= 16u;
         const uint32_t lo = sl ? r1 : r0, hi = sl ? r2 : r1;
         const uint32_t nwc = __builtin_amdgcn_alignbit(hi, lo, 2u * no);
-        const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
-        const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
+        const uint32_t ns1 = OTH ? okey[(nwc >> 8) & 1023u] : lut0[(nwc >> 8) & 1023u];
+        const uint32_t ns2 = OTH ? okey[(nwc >> 4) & 1023u] : lut0[(nwc >> 4) & 1023u];
 
         // ---- this probe's accounting, in the shadow of the LUT reads ----
         const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;   // equal bases before cur, 0..4
@@ -888,8 +1079,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         const bool svc = (mx >= 15) | (ncur >= limc) | straddle;
         SNK_TRACE_REC(3u, vb + c, (uint32_t)(T0 + (int32_t)t), (r << 24) | (m ? 0x800000u : 0u) | (valid ? 0x400000u : 0u) | (e2 & 0x3FFFFFu), vb + c);
 #ifdef SNK_STATS
-        if (stat_first) SNK_COUNT(15);
-        if (svc) {          // why lanes ask for service (a lane may have several reasons; an exit may serve several lanes)
+        if (!OTH && stat_first) SNK_COUNT(15);                    // (the other-case mode keeps its account undistorted: no atomics per trip)
+        if (!OTH && svc) {          // why lanes ask for service (a lane may have several reasons; an exit may serve several lanes)
             if ((int32_t)lit >= 15) SNK_COUNT(16);
             if (b >= 4u) SNK_COUNT(17);
             if ((int32_t)op - olimZ + 14 >= 15) SNK_COUNT(18);
@@ -898,7 +1089,9 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
             if (straddle) SNK_COUNT(22);
         }
 #endif
-        if (__builtin_amdgcn_ballot_w64(svc) != 0ull) break;
+        // one wave-uniform exit; in the other-case mode (compiled code, a stretch is ~100 trips) a lane that needs service
+        // or has reached the end of its stretch leaves alone and the others walk on
+        if (OTH ? svc : __builtin_amdgcn_ballot_w64(svc) != 0ull) break;
 
         // ---- commit ----
         op = m ? opn : op; anchor_c = m ? ncur : anchor_c;
@@ -909,11 +1102,20 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #ifdef SNK_STATS
     const unsigned long long stat_t1 = clock64();
     P.loop += stat_t1 - stat_t0; P.entries++;
+    if (OTH) {      // wave trips of this run = the most any lane made; lane-trips = their sum (every lane keeps the wave's sums)
+        unsigned int mx = stat_otrips, sm = stat_otrips;
+        for (int o = 32; o; o >>= 1) { const unsigned int v = (unsigned int)__shfl_xor((int)mx, o), w2 = (unsigned int)__shfl_xor((int)sm, o); mx = v > mx ? v : mx; sm += w2; }
+        P.otrips += mx; P.olanes += sm; P.oruns++;
+    }
 #endif
     // hand every lane over in the state "table operations of the probe at c done, match not evaluated"
     L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
     w.rb = 0x80000000u;                                           // reservoir not kept: the head re-seats it
-    if (EXC) {
+    if (OTH) {
+        const uint32_t cur = vb + c, cand = (uint32_t)(T0 + (int32_t)t);
+        if (!snk_exc_finish_win(L, cur, cand, valid, snk_fetch32(L.s, cur), snk_fetch32m(L.s, cur)))
+            snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
+    } else if (EXC) {
         const uint32_t cur = vb + c;
         uint32_t cand = (uint32_t)(T0 + (int32_t)t);
         if (valid && !snk_exc_clean(L, cand)) {                   // an exception near the candidate: the real bytes decide
@@ -995,6 +1197,7 @@ __device__ __forceinline__ void snk_fast_lane_init(SnkFastLane &L, const SnkTabl
     const uint32_t lx = T.len[job.xi];
     const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
     L.s.arena = (snk_g8 *)T.packed_arena;
+    L.s.marena = (snk_g8 *)T.mask_arena;
     L.s.xoff = T.packed_off[job.xi];
     L.s.yoff = job.yi >= 0 ? T.packed_off[job.yi] : SNK_PAD;         // zero region at the arena start
     L.s.lx = lx;
@@ -1036,7 +1239,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 
 #ifdef SNK_STATS
     const unsigned long long stat_w0 = clock64();
-    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
+    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
     const bool lane_on = lane < lanes;
@@ -1144,6 +1347,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                     L.ry = L.fy ? T.exc_runs + 2u * T.exc_roff[job.yi] : nullptr;
                     L.ri = 0u; L.ron_y = false;
                     L.xlim = 0u; L.site_lo = L.site_hi = 0u;
+                    L.olo = L.olim = 0u; L.oscan = 0xFFFFFFFFu;
                     // the start state (position 0 in every slot, or x's prefix snapshot) may point at exceptions of x
                     L.mask_until = L.fx ? L.pos + 65536u : 0u;
                 }
@@ -1159,7 +1363,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 atomicAdd(&S[13], P.loop); atomicAdd(&S[14], (unsigned long long)P.entries);
                 atomicAdd(&S[24], P.finish); atomicAdd(&S[25], P.rounds_cyc); atomicAdd(&S[26], (unsigned long long)P.rounds);
                 atomicAdd(&S[27], P.prologue); atomicAdd(&S[28], P.probe); atomicAdd(&S[29], P.top);
-                atomicAdd(&S[30], (unsigned long long)P.jobs); atomicAdd(&S[31], 1ull);
+                atomicAdd(&S[30], (unsigned long long)P.jobs); atomicAdd(&S[31], 1ull); atomicAdd(&S[23], P.other); atomicAdd(&S[48], P.otrips); atomicAdd(&S[49], P.olanes); atomicAdd(&S[50], (unsigned long long)P.oruns);
             }
 #endif
             return;
@@ -1222,12 +1426,38 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 } else if (cur >= 4u && cur + 12u <= lx)   snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
                 ok = parked || snk_fast_eligible<EXC>(L);
             }
+            bool oel = false;
+            if (EXC) {
+                // lanes served at a site that stand inside an other-case stretch (a window of class 01 only) walk it in the steady
+                // loop's other-case mode instead of one general probe per round -- TOGETHER: the lanes gathered at the site reach
+                // the stretch proper a few general probes apart, so the mode starts once no served lane needs a general probe any
+                // more (else the first lane to arrive would walk its whole stretch alone, then the next one, ...)
+                oel = !ok && L.cur + L.step <= L.mfl1 && L.step == 1u && L.nb < 63u + SNK_FAST_MAXLIT &&
+                      L.op + SNK_FAST_ZONE <= L.olimit && L.cur >= L.xlim && snk_exc_other_ready(L);
+                if (__any(oel) && !__any(!ok && !oel)) {
+#ifdef SNK_STATS
+                    const unsigned long long stat_q0 = clock64();
+#endif
+                    if (oel) {
+                        const uint32_t cur = L.cur, lx = L.s.lx;
+                        if (cur >= lx + 4u) snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
+                        else                snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
+                        if (L.mask_until < L.olim + 65536u) L.mask_until = L.olim + 65536u;     // its puts point into the stretch
+                        snk_fast_steady<false, true, false, true>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)T.mask_arena, tbl, bm, gt,
+                                                                  (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu, T.lut_okey SNK_PROF_PASS);
+                    }
+#ifdef SNK_STATS
+                    P.other += clock64() - stat_q0;
+#endif
+                    continue;
+                }
+            }
             if (__builtin_expect(!__any(!ok), 1)) { flushing = false; break; }
 #ifdef SNK_STATS
             const unsigned long long stat_g0 = clock64();
 #endif
             bool stat_done = false;
-            if (!ok && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; }   // frame complete
+            if (!ok && !oel && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; }   // frame complete
             (void)stat_done;
 #ifdef SNK_STATS
             P.jobs += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(stat_done));
@@ -1242,7 +1472,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
         if (have && !parked && waiting == 0u)
             snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
-                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu SNK_PROF_PASS);
+                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu, T.lut_okey SNK_PROF_PASS);
     }
 }
 

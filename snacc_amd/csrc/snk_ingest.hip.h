@@ -70,8 +70,10 @@ __global__ void snk_pack_kernel(const uint8_t *bytes, uint64_t n, uint8_t *packe
     }
 }
 
-// The mask arena of the 2-bit kernel (sequences with exceptions): same layout as the packed bytes, 11 where the byte
-// is not one of ACGT, 00 elsewhere and behind the end.
+// The mask arena of the 2-bit kernel (sequences with exceptions): same layout as the packed bytes, one 2-bit CLASS per base:
+// 00 one of the set's four letters (ACGT, or acgt in a lower-case set) and behind the end, 01 the same letter in the OTHER
+// case (soft-masked stretches), 11 any other byte (N, IUPAC codes, ...).  The 2-bit code (c >> 1) & 3 is the same for both
+// cases of a letter, so (code, class) names the byte exactly unless the class is 11.
 __global__ void snk_packmask_kernel(const uint8_t *bytes, uint64_t n, uint8_t *mask, uint32_t lcase)
 {
     uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,7 +83,12 @@ __global__ void snk_packmask_kernel(const uint8_t *bytes, uint64_t n, uint8_t *m
         uint32_t v = 0;
         for (uint32_t b = 0; b < 4u; ++b) {
             const uint64_t i = o * 4 + b;
-            if (i < n) { const uint32_t c = bytes[i]; if (!(c == ('A' | lcase) || c == ('C' | lcase) || c == ('G' | lcase) || c == ('T' | lcase))) v |= 3u << (2u * b); }
+            if (i < n) {
+                const uint32_t c = bytes[i], u = c & ~0x20u;
+                const bool letter = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+                if (!letter) v |= 3u << (2u * b);
+                else if ((c & 0x20u) != lcase) v |= 1u << (2u * b);
+            }
         }
         mask[o] = (uint8_t)v;
     }

@@ -44,3 +44,13 @@ def fast_sizes(seqs, header_bytes=7, exc_limit=128, lower=False, far=False):
         raise RuntimeError(f"emulated kernel reported status {rc}")
     return singles, pairs
 
+
+
+def other_mode_trips():
+    """Trips the steady loop's other-case mode has made so far in this process (soft-masked stretches)."""
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.emu_fast_sizes.restype = ctypes.c_int
+    _lib.emu_other_mode_trips.restype = ctypes.c_ulonglong
+    return int(_lib.emu_other_mode_trips())

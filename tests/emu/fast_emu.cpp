@@ -43,6 +43,13 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         }
         if (n_slots >= (int)SNK_FSLOTS) return -1;         // (the last slot stays free: "nothing owed" puts go there)
     }
+    std::vector<uint16_t> okey(1024, 0);               // the other case's 5-mers: shared slot, or 0x1000 | liblz4's hash
+    for (uint32_t k = 0; k < 1024; ++k) {
+        uint8_t b[5];
+        for (int i = 0; i < 5; ++i) b[i] = (uint8_t)(code2byte[(k >> (2 * i)) & 3] ^ 0x20);
+        const uint32_t h = host_hash5(b);
+        okey[k] = h2s[h] != 0xFFFF ? h2s[h] : (uint16_t)(0x1000u | h);
+    }
     std::vector<uint8_t> ok((size_t)n, 0), exc((size_t)n, 0);
     std::vector<uint32_t> poff((size_t)n, 0), boff((size_t)n, 0), len((size_t)n), spos((size_t)n), eoff((size_t)n, 0xFFFFFFFFu);
     std::vector<std::vector<uint32_t>> flags((size_t)n);
@@ -85,8 +92,12 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
             if (!ok[g]) continue;
             for (uint64_t i = 0; i < lens[g]; ++i)
                 arena[poff[g] + (i >> 2)] |= (uint8_t)(((seqs[g][i] >> 1) & 3u) << (2u * (i & 3u)));
-            for (uint64_t i = 0; i < lens[g]; ++i)
-                if (!acgt(seqs[g][i])) marena[poff[g] + (i >> 2)] |= (uint8_t)(3u << (2u * (i & 3u)));
+            for (uint64_t i = 0; i < lens[g]; ++i)          // class arena: 00 the set's letters, 01 the other case, 11 another byte
+                if (!acgt(seqs[g][i])) {
+                    const uint8_t u = (uint8_t)(seqs[g][i] & ~0x20u);
+                    const bool letter = u == 'A' || u == 'C' || u == 'G' || u == 'T';
+                    marena[poff[g] + (i >> 2)] |= (uint8_t)((letter ? 1u : 3u) << (2u * (i & 3u)));
+                }
         }
     }
     std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), snap_gen((size_t)n * 4096, 0), status(1, 0);
@@ -110,7 +121,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     T.packed_arena = arena.data(); T.mask_arena = marena.data(); T.packed_off = poff.data(); T.len = len.data();
     T.bytes_arena = bytes.data(); T.bytes_off = boff.data(); T.zero_pad = zero.data();
     T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data(); T.snap_gen = snap_gen.data();
-    T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.header_bytes = header_bytes;
+    T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.lut_okey = okey.data(); T.header_bytes = header_bytes;
     T.exc_flags = fl.data(); T.exc_off = eoff.data(); T.ovf = ovf.data(); T.exc_runs = runs.data(); T.exc_roff = roff.data();
 
     blockDim.x = 64; threadIdx.x = 0; blockIdx.x = 0;
@@ -150,3 +161,5 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     return (int)status[0];
 }
 
+
+extern "C" unsigned long long emu_other_mode_trips(void) { return snk_emu_oth_trips; }

@@ -15,6 +15,7 @@ struct SnkEmuDim { unsigned x, y, z; };
 static SnkEmuDim threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, blockDim = {64, 1, 1}, gridDim = {1, 1, 1};
 
 static uint8_t snk_lds8[160 * 1024] __attribute__((aligned(16)));
+static unsigned long long snk_emu_oth_trips = 0;      // trips of the steady loop's other-case mode (the tests check that it ran)
 
 static inline int __any(int p) { return p != 0; }
 static inline int __all(int p) { return p != 0; }

@@ -313,6 +313,62 @@ def test_soft_masked_genomes_stay_on_the_2bit_kernel(hip, oracle_mod):
         assert np.array_equal(p, exp_p), (opts, np.argwhere(p != exp_p)[:8].tolist())
 
 
+def test_exceptions_at_the_bench_shape_1mbp_84_chains(hip, oracle_mod):
+    """The exception machinery at the shape the kernel is benchmarked on: 128 genomes of 1 Mbp -- soft-masked (1 / 5 / 20 %
+    lower case in stretches of ~500 bases, some with n runs and IUPAC codes inside the stretches), scattered IUPAC codes
+    (100 and 1000 per Mbp), N runs, relatives in which the same region is masked in one genome and not in the other, and
+    pure ones -- 84 rows x 128 columns (84 chains per workgroup, every lane of a wave at work, sites gathered, the steady
+    loop's other-case mode, mask windows), EVERY size compared with the oracle.  Also far chains on the pure pairs'
+    geometry (option far_lanes: a measured negative, kept for reproduction) must not change a size."""
+    from oracle.loader import pairs_mt
+    o = oracle_mod
+    rng = np.random.default_rng(84)
+    n, L = 128, 1_000_000
+    iupac = np.frombuffer(b"RYKMSWBDHVNryn", dtype=np.uint8)
+    anc = [o.lcg_genome(8400 + a, L) for a in range(4)]
+    seqs = []
+    for i in range(n):
+        a = (o.lcg_mutant(anc[i % 4], 500 + i) if i % 3 else o.lcg_genome(8500 + i, L)).copy()
+        kind = i % 8
+        if kind in (1, 2, 3):                                   # soft-masked: 1 / 5 / 20 %
+            pct = (1, 5, 20)[kind - 1]
+            for s0 in rng.integers(0, L - 800, max(1, L * pct // 100 // 500)):
+                a[s0:s0 + int(rng.integers(300, 700))] |= 0x20
+            if i % 16 == kind:                                  # ... with n runs and IUPAC codes inside the stretches
+                low = np.flatnonzero(a & 0x20)
+                for p0 in rng.choice(low, 12):
+                    a[p0:p0 + int(rng.integers(1, 25))] = ord("n")
+                a[rng.choice(low, 20)] = rng.choice(iupac, 20)
+        elif kind == 4:
+            a[rng.integers(0, L, 100)] = rng.choice(iupac, 100)
+        elif kind == 5:
+            a[rng.integers(0, L, 1000)] = rng.choice(iupac, 1000)
+        elif kind == 6:
+            for s0 in rng.integers(0, L - 2000, 10):
+                a[s0:s0 + int(rng.integers(10, 1500))] = ord("N")
+        seqs.append(a)
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        assert ctx.num_packed == n and ctx.fast_chains() == 84
+        s, p = ctx.singles(), ctx.pairs(0, 84)
+    assert np.array_equal(s[:4], np.array([o.lz4f_size(x) for x in seqs[:4]], dtype=np.uint32))
+    want = pairs_mt(seqs, 0, 84, _threads())
+    assert np.array_equal(p, want), np.argwhere(p != want)[:8].tolist()
+
+
+def test_far_chains_option_changes_no_size(hip, oracle_mod):
+    """far_lanes / far_waves (extra waves whose chains keep their tables in global memory: profiles/r03_far_chains.json, a
+    measured negative, off by default): 300 pure genomes of 100 kbp (90 000 pairs: a launch large enough for the far waves to
+    be used), every size equal to the oracle's with 8 x 4 far chains."""
+    from oracle.loader import pairs_mt
+    o = oracle_mod
+    seqs = [o.lcg_genome(1 + i, 100_000) for i in range(300)]
+    with hip.HipContext(0, far_lanes=8, far_waves=4) as ctx:
+        ctx.upload(seqs)
+        p = ctx.pairs()
+    assert np.array_equal(p, pairs_mt(seqs, 0, 300, _threads()))
+
+
 def test_lower_case_sets_run_on_the_2bit_kernel(hip, oracle_mod):
     """A set whose letters are acgt runs on the 2-bit kernel like an upper-case one (its LUTs are made from liblz4's
     hashes of the lower-case 5-mers; upper-case stretches are then the exceptions); the case goes by the set's majority,

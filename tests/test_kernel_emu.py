@@ -169,6 +169,48 @@ def test_emu_soft_masked_stretches():
     seqs[3][-400:] |= 0x20                              # ... and at the end (the seam of every pair with it in front)
     seqs[0][65000:66100] |= 0x20                        # ... across a block edge
     assert all(_packable(x, 65536) for x in seqs)       # (all of them run in the emulated kernel)
+    from emu import other_mode_trips
+    before = other_mode_trips()
+    check(seqs, exc_limit=65536)
+    assert other_mode_trips() - before > 20000          # the stretches were walked in the loop's other-case mode
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_emu_soft_masked_fuzz(seed):
+    """The general probe on (code, class) windows: lower-case stretches with n runs, IUPAC codes of both cases and single
+    bases of the other case inside and next to them, tandem repeats that cross case boundaries, and relatives in which the
+    same region is lower case in one genome and upper case in the other (equal 2-bit codes, different bytes: no match)."""
+    rng = np.random.default_rng(9000 + seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = int(rng.choice([int(rng.integers(70000, 160000)), int(65536 * rng.integers(1, 3) + rng.integers(-20, 21))]))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        base = rng.choice(acgt, n)
+    elif kind == 1:                                   # tandem repeat with substitutions: long matches across the case boundaries
+        unit = rng.choice(acgt, int(rng.integers(3, 900)))
+        base = np.tile(unit, n // len(unit) + 1)[:n].copy()
+        m = rng.random(n) < 0.004
+        base[m] = rng.choice(acgt, int(m.sum()))
+    else:
+        base = oracle.lcg_genome(9100 + seed, n)
+    seqs = [base.copy()]
+    for v in range(3):
+        a = oracle.lcg_mutant(base, 40 + v)[int(rng.integers(0, 50)):].copy() if v else base.copy()
+        a = _soft_masked(rng, a, int(rng.choice([2, 10, 30])), int(rng.choice([60, 300, 900])))
+        for _ in range(int(rng.integers(0, 6))):           # n runs / IUPAC codes / other-case singles, in and near the stretches
+            s0 = int(rng.integers(0, len(a) - 50))
+            what = int(rng.integers(0, 4))
+            if what == 0:
+                a[s0:s0 + int(rng.integers(1, 40))] = ord("n")
+            elif what == 1:
+                a[s0] = rng.choice(np.frombuffer(b"RYKMryswN", dtype=np.uint8))
+            elif what == 2:
+                a[s0] ^= 0x20
+            else:
+                a[s0:s0 + int(rng.integers(1, 30))] = ord("N")
+        seqs.append(a)
+    seqs.append(rng.choice(acgt, int(rng.integers(66000, 90000))))
+    seqs[-1][2000:2600] |= 0x20
     check(seqs, exc_limit=65536)
 
 

@@ -54,6 +54,11 @@ for kind in KINDS:
         L_.snk_debug_stats(st)
         names = ["steady exits", "general probes", "sentinel reads", "flushes", "byte matches", "site arrivals", "sentinel puts", "ovf-only puts"]
         print("   stats (upload + 4 launches):", {nm: int(st[i]) for i, nm in enumerate(names) if i != 7})
+        if st[40]:
+            print("   probe stamps (cycles, first lane): windows %d, owed put %d, key %d, get+put %d, finish %d" % tuple(int(st[40 + i]) for i in range(5)))
+        if st[23]:
+            print(f"   other-case mode: {st[23] / st[7]:.1%} of the wave cycles; {int(st[50]):,} runs, {st[48] / max(1, st[50]):.0f} wave trips per run, "
+                  f"{st[49] / max(1, st[48]):.1f} lanes per trip, {st[23] / max(1, st[48]):,.0f} cycles per wave trip")
         if st[14]:
             print(f"   wave cycles {int(st[7]):,}: in the loop {st[13] / st[7]:.1%}, loop entries {int(st[14]):,}, per entry: outside {(st[7] - st[13]) / st[14]:,.0f} cycles"
                   f" (finish {st[24] / st[14]:,.0f}, general rounds {st[25] / st[14]:,.0f} in {st[26] / st[14]:.2f} rounds)"
