@@ -77,6 +77,7 @@ struct snk_ctx_impl {
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
     bool dfl_serial = false, dfl_kmer = true, dfl_norestart = false;
     uint8_t *d_bytes = nullptr, *d_packed = nullptr, *d_pmask = nullptr, *d_zero = nullptr;
+    uint16_t *d_slots = nullptr;     // slot stream of the byte kernels (2 bytes per byte of the ASCII arena)
     const uint8_t **d_bytes_ptr = nullptr; uint32_t *d_packed_off = nullptr, *d_bytes_off = nullptr;
     uint32_t *d_len = nullptr, *d_snap_pos = nullptr, *d_snap_out = nullptr;
     uint32_t *d_snap_fast = nullptr, *d_snap_gen = nullptr;
@@ -121,7 +122,7 @@ template <typename T> struct DevTemp {
 
 void free_sequences(snk_ctx_impl *c)
 {
-    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_pmask); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
+    dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_pmask); dfree(c->d_slots); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
     dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0; c->ovf_in_flight = false;
     dfree(c->d_exc_runs); dfree(c->d_exc_roff);
@@ -189,7 +190,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
     T.exc_runs = c->d_exc_runs; T.exc_roff = c->d_exc_roff;
     T.exc_flags = c->d_exc_flags; T.exc_off = c->d_exc_off; T.lut_h2s = c->d_lut_h2s; T.lut_s2h = c->d_lut_s2h; T.lut_okey = c->d_lut_okey; T.ovf = c->d_ovf;
-    T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
+    T.slots = c->d_slots; T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
 
@@ -911,6 +912,24 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
                 HIPCHK(c, hipMemcpy(c->d_lut_h2c4, h2c.data(), 16384, hipMemcpyHostToDevice));
                 c->oneshot_compact_ok = true;
             }
+        }
+    }
+
+    // ---- slot stream of the byte kernels (linked mode) ------------------------------------------
+    // needed when some pair of > 64 KiB cannot run on the 2-bit kernel: a sequence that is not packed, or force_generic
+    {
+        bool need = c->force_generic;
+        for (size_t g = 0; g < n && !need; ++g) need = !c->is_packed[g];
+        if (need && !c->bytes_legacy && c->max_len > 0 && (uint64_t)c->max_len * 2u > SNK_BLOCK) {
+            HIPCHK(c, hipMalloc((void **)&c->d_slots, btot * sizeof(uint16_t)));
+            HIPCHK(c, hipMemsetAsync(c->d_slots, 0, btot * sizeof(uint16_t), c->stream));
+            for (size_t g = 0; g < n; ++g) {
+                if (lens[g] < 5) continue;
+                uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 2048);
+                hipLaunchKernelGGL(snk_slotstream_kernel, dim3(grid), dim3(256), 0, c->stream, c->d_bytes + boff[g], (uint64_t)lens[g],
+                                   c->compact_ok ? (const uint16_t *)c->d_lut_h2c : (const uint16_t *)nullptr, c->d_slots + boff[g]);
+            }
+            HIPCHK(c, hipGetLastError());
         }
     }
 

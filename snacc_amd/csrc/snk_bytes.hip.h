@@ -317,8 +317,14 @@ __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTab
     } else {
         L.cur = next; L.step = s3 ? s3 : 1u; L.nb++; L.pending = false;
     }
-    // seat the reservoir for the tight loop when the new cursor allows it
+    // seat the reservoir for the tight loop when the new cursor allows it (slot-stream loop: only which source serves the cursor)
     const uint32_t nc = L.cur;
+    if (!ONESHOT && T.slots) {
+        if (nc >= L.s.lx + 4u)                     { L.w.soff = L.s.yoff; L.w.org = L.s.lx; L.w.lim = 0xFFFFFFFFu; }
+        else if (nc >= 4u && nc + 8u <= L.s.lx)    { L.w.soff = L.s.xoff; L.w.org = 0u; L.w.lim = L.s.lx - 8u; }
+        else                                       L.w.lim = 0u;
+        return false;
+    }
     if (nc >= L.s.lx + 4u)                         snk_bwin_init(L.w, L.s.arena, L.s.yoff, L.s.lx, 0xFFFFFFFFu, nc);
     else if (nc >= 4u && nc + 8u <= L.s.lx)        snk_bwin_init(L.w, L.s.arena, L.s.xoff, 0u, L.s.lx - 8u, nc);
     else                                           L.w.lim = 0u;
@@ -408,6 +414,83 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
     }
 }
 
+
+// Tight loop of the linked mode on the SLOT STREAM (T.slots): no hash arithmetic, no hash -> slot LUT and no register
+// reservoir on the dependent chain.  The next probe's data -- the slots of cur-2 and cur (one 8-byte load from the slot
+// stream) and the 12-byte compare window of the cursor (one load from the ASCII arena) -- are loaded directly as soon as
+// the next cursor is known; both hit the L1 (the wave's chains walk the same suffix).  Cursors whose 12-byte window does
+// not lie inside one sequence (stream start, seam) go through the general probe, as before.
+struct __attribute__((packed)) SnkU64p { uint64_t v; };
+template <int CAP>
+__device__ __forceinline__ void snk_bytes_loop2(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                                uint32_t *out, uint32_t *status)
+{
+    snk_g8 *const arena = L.s.arena;
+    const SNK_AS1 uint16_t *const slots = (const SNK_AS1 uint16_t *)T.slots;
+    for (;;) {
+        uint32_t cur, next;
+        for (;;) {
+            cur = L.cur;
+            next = cur + L.step;
+            const bool pre = (next > L.mfl1) | (cur > L.w.lim) | (cur < L.w.org + 4u);     // w: which source serves the cursor (soff, org, lim)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
+            if (pre && snk_bytes_iter_slow<CAP, false>(L, T, tbl, bm, out, status)) return;
+        }
+        // data of the first probe
+        uint32_t so = L.w.soff + (cur - L.w.org);                                           // ASCII arena offset of the cursor
+        uint64_t sv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)so - 2u))->v;               // slots of cur-2 .. cur+1
+        const SNK_AS1 SnkU96 *wp = (const SNK_AS1 SnkU96 *)(arena + (size_t)so - 4u);
+        SnkW12 w; w.a = wp->a; w.b = wp->b; w.c = wp->c;
+        const uint32_t olim6 = L.olimit - 6u;
+
+        for (;;) {
+            uint32_t cand; bool valid;
+            snk_bytes_table<CAP, false>(L, tbl, bm, cur, (uint32_t)(sv >> 32) & 0xFFFFu, (uint32_t)sv & 0xFFFFu, cand, valid);
+            const SnkW12 wd = snk_bfetch12(L.s, cand);
+
+            const uint32_t x0 = w.a ^ wd.a, x1 = w.b ^ wd.b, x2 = w.c ^ wd.c;
+            uint32_t fh = (uint32_t)__builtin_ctz(x2 | 0x80000000u) >> 3;
+            fh = x2 ? fh : 4u;
+            const uint32_t f = x1 ? ((uint32_t)__builtin_ctz(x1) >> 3) : 4u + fh;
+            const uint32_t eq = x0 ? ((uint32_t)__builtin_clz(x0) >> 3) : 4u;
+            const bool m = valid & (x1 == 0u);
+            uint32_t e2 = cur + f;
+            e2 = e2 < L.mlimit ? e2 : L.mlimit;
+            const uint32_t s3 = L.nb >> 6;
+            const uint32_t nstep = m ? 1u : (s3 ? s3 : 1u);
+            const uint32_t ncur = m ? e2 : next;
+            const uint32_t nnext = ncur + nstep;
+
+            // ---- the next probe's data: direct loads (in flight during the bookkeeping) ----
+            const uint32_t nso = so + (ncur - cur);
+            const uint64_t nsv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)nso - 2u))->v;
+            const SNK_AS1 SnkU96 *nwp = (const SNK_AS1 SnkU96 *)(arena + (size_t)nso - 4u);
+            SnkW12 nw; nw.a = nwp->a; nw.b = nwp->b; nw.c = nwp->c;
+
+            // ---- bookkeeping of this probe ----
+            const uint32_t anchor0 = L.anchor, op0 = L.op;
+            uint32_t lit = cur - anchor0;
+            uint32_t b = eq < lit ? eq : lit;
+            b = b < cand ? b : cand;
+            lit -= b;
+            const uint32_t opn = op0 + lit + 3u;
+            const bool rare = m & ((b == 4u) | (f == 8u) | (lit >= 15u) | (opn > olim6));
+            const bool pre = (nnext > L.mfl1) | (ncur > L.w.lim);
+            L.op = m ? opn : op0;
+            L.anchor = m ? e2 : anchor0;
+            L.step = nstep;
+            L.nb = m ? 63u : L.nb + 1u;
+            L.cur = ncur;
+            L.pending = m;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare | pre) != 0ull, 0)) {
+                if (rare) snk_bytes_match_slow(L, cur, cand, anchor0, op0);
+                break;
+            }
+            cur = ncur; next = nnext; so = nso; sv = nsv; w = nw;
+        }
+    }
+}
+
 // grid: one workgroup per `lanes*waves` jobs; dynamic LDS = LUT_B + CHAIN_B per chain.
 template <int CAP, bool ONESHOT>
 __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
@@ -492,7 +575,8 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
     L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
-    snk_bytes_loop<CAP, ONESHOT>(L, T, tbl, bm, out, status);
+    if (!ONESHOT && T.slots) snk_bytes_loop2<CAP>(L, T, tbl, bm, out, status);
+    else                     snk_bytes_loop<CAP, ONESHOT>(L, T, tbl, bm, out, status);
 }
 
 __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,

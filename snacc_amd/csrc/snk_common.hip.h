@@ -74,6 +74,8 @@ struct SnkTables {
     const uint16_t *lut_slot;         // [1024]  5-mer code -> table slot (0..893); colliding 5-mers share one
     const uint16_t *lut_h2c;          // [4096]  compact byte kernel: hash -> slot 0..CAP-1, 0xFFFF = not in the resident set
     const uint16_t *lut_h2c4;         // [8192]  the same for the one-shot hash of 4 bytes
+    const uint16_t *slots;            // slot stream of the byte kernels: [ASCII arena offset + p] = table slot of the 5 bytes at p
+                                      // (NULL: every resident pair runs on the 2-bit kernel or in one-shot mode)
     const uint8_t  *zero_pad;         // >= 2*SNK_PAD zero bytes
     // 2-bit kernel on sequences with a few non-ACGT bytes ("exceptions": N runs, IUPAC codes; snk_fast.hip.h)
     const uint32_t *exc_flags;        // 1 bit per 16 bases: an exception lies within bases [16g - 16, 16g + 32)

@@ -117,6 +117,26 @@ __global__ void snk_hashset_kernel(const uint8_t *bytes, uint64_t n, uint32_t *s
         if (local[t]) atomicOr(&set[t], local[t]);
 }
 
+// The slot stream of the byte kernels (linked mode): slot[p] = table slot of the 5 bytes at p -- liblz4's 12-bit hash, or
+// its renaming through the compact LUT -- for every position of a resident sequence (0 where fewer than 5 bytes are left:
+// never probed).  Computed once per upload, it takes the 64-bit multiply and the hash -> slot LUT off the dependent
+// chain of every probe: the tight loop loads the slots of cur-2 and cur with one 8-byte load.
+__global__ void snk_slotstream_kernel(const uint8_t *bytes, uint64_t n, const uint16_t *lut /* NULL: slot = hash */, uint16_t *slots)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) {
+        uint32_t v = 0u;
+        if (p + 5u <= n) {
+            uint64_t w = 0;
+            for (uint32_t b = 0; b < 5u; ++b) w |= (uint64_t)bytes[p + b] << (8u * b);
+            const uint32_t h = (uint32_t)(((w << 24) * 889523592379ull) >> 52);
+            v = lut ? lut[h] : h;
+        }
+        slots[p] = (uint16_t)v;
+    }
+}
+
 // Same for the one-shot hash (13 bits of 4 bytes, positions p <= n-4); `set` has 256 words.
 __global__ void snk_hashset4_kernel(const uint8_t *bytes, uint64_t n, uint32_t *set)
 {
