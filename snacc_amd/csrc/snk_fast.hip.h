@@ -688,6 +688,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 #define SNK_PADE
 #endif
 #define SNK_STEADY_TABLE \
+    SNK_STEADY_ENTER \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
@@ -723,6 +724,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 #define SNK_FAR_LOADMOD "sc1"      /* device scope: served by the L2, the line is not kept in the CU's L1 (which the windows of y live in) */
 #endif
 #define SNK_STEADY_TABLE_FAR \
+    SNK_STEADY_ENTER \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur */ \
     "v_lshl_add_u32 v90, %[s1], 2, %[gtb]\n\t" \
@@ -815,6 +817,30 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 #define SNK_STEADY_MASKOR \
     "v_alignbit_b32 v119, v119, v118, v109\n\t" \
     "v_or_b32_e32 v113, v113, v119\n\t"
+// diagnostic builds only (-DSNK_PARK=1 / 2, measured negatives of round 3): at the loop's exit test,
+// lanes whose ONLY reason is their limit (1: an exception site, 2: the end of their block when the wave's lanes end their
+// blocks at the same place of y) are parked -- taken out of EXEC, registers frozen in the state every lane leaves the loop
+// in -- and the others walk on, instead of one wave exit and re-entry per lane.  Nothing is added to the trip itself.
+#ifdef SNK_PARK
+#define SNK_STEADY_ENTER "s_mov_b64 %[se], exec\n\t"
+#define SNK_STEADY_PARK \
+    "s_cmp_eq_u64 %[blk], 0\n\t"                       /* blk: the lanes whose limit may park them; 0 = none */ \
+    "s_cbranch_scc1 .Lsnk_leave%=\n\t" \
+    "v_cmp_ge_u32_e64 %[ss], %[c], %[limc]\n\t"        /* the next cursor is at the lane's real limit ... */ \
+    "s_and_b64 %[ss], %[ss], %[blk]\n\t"               /* ... which is its site */ \
+    "v_cmp_lt_i32_e32 vcc, 14, v125\n\t"               /* literal run, back-extension, output budget */ \
+    "s_andn2_b64 %[ss], %[ss], vcc\n\t"                /* the lanes to park */ \
+    "s_or_b64 vcc, vcc, %[st]\n\t" \
+    "s_andn2_b64 vcc, vcc, %[ss]\n\t"                  /* a lane with another reason: leave */ \
+    "s_cbranch_vccnz .Lsnk_leave%=\n\t" \
+    "s_andn2_b64 exec, exec, %[ss]\n\t" \
+    "s_cbranch_execnz 1b\n\t" \
+    ".Lsnk_leave%=:\n\t" \
+    "s_mov_b64 exec, %[se]\n\t"
+#else
+#define SNK_STEADY_ENTER
+#define SNK_STEADY_PARK
+#endif
 #define SNK_STEADY_REST_X(LIM, MASKOR) SNK_STEADY_REST_XX(LIM, MASKOR, "1", "0")
 #define SNK_STEADY_REST_XX(LIM, MASKOR, W1, W0) \
     "s_waitcnt vmcnt(" W1 ")\n\t" SNK_PADD \
@@ -852,17 +878,19 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     "v_cmp_ge_u32_e64 %[st], %[c], " LIM "\n\t" \
     "s_or_b64 vcc, vcc, %[st]\n\t" \
     "s_cbranch_vccz 1b\n\t" \
+    SNK_STEADY_PARK \
     "s_waitcnt lgkmcnt(0)\n\t"
 #define SNK_STEADY_OPERANDS SNK_STEADY_OPERANDS_X()
 #define SNK_STEADY_OPERANDS_FAR SNK_STEADY_OPERANDS_X(, [gtb] "v"(gtb), [ftab] "s"(ftab), [vbm2] "v"(vb - 2u), [k17] "s"(131071))
 #define SNK_STEADY_OPERANDS_X(...) \
-    : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
-      [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
-      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), \
-      [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st) \
+    /* ("+&": an input-only operand of equal value -- blk and sl both start as 0 -- must not share the register) */ \
+    : [c] "+&v"(c), [wc] "+&v"(wc), [s1] "+&v"(s1), [s2] "+&v"(s2), [r0] "+&v"(r0), [r1] "+&v"(r1), \
+      [rbc] "+&v"(rbc), [nxoff] "+&v"(nxoff), [anchor] "+&v"(anchor_c), [op] "+&v"(op), \
+      [opn] "+&v"(opn), [ns2] "+&v"(ns2), [sm] "+&s"(sm), [sl] "+&s"(sl), \
+      [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [se] "=&s"(se) \
     : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
       [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
-      [arena] "s"(arena), [marena] "s"(marena) __VA_ARGS__ \
+      [arena] "s"(arena), [marena] "s"(marena), [blk] "s"(blk) __VA_ARGS__ \
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
@@ -968,7 +996,18 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #ifndef SNK_HOST_EMU
     if (ASM) {
         uint32_t lit;
-        uint64_t sv, ss, st;                                          // wave masks: valid, straddle, limit
+        uint64_t sv, ss, st, se;                                      // wave masks: valid, straddle, limit; EXEC at entry
+        // (EXC) the lanes whose limit is an exception site: parked at the loop's exit test instead of forcing a wave exit each
+        uint64_t blk = 0ull;
+#if defined(SNK_PARK) && SNK_PARK == 1          /* diagnostic: park at exception sites */
+        if (EXC) blk = __builtin_amdgcn_ballot_w64(lim_abs == L.xlim);
+#elif defined(SNK_PARK) && SNK_PARK == 2        /* diagnostic: park at block ends when the wave's lanes end their blocks at the same place of y */
+        if (!EXC && !FAR && L.cur >= L.s.lx &&
+            __all((L.mfl1 - L.s.lx) == (uint32_t)__builtin_amdgcn_readfirstlane((int)(L.mfl1 - L.s.lx)) && L.cur >= L.s.lx))
+            blk = __builtin_amdgcn_ballot_w64(lim_abs == L.mfl1);
+#endif
+        blk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(blk >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)blk);                      // (an SGPR pair for the asm, whatever the compiler thinks of it)
         uint64_t sm = __builtin_amdgcn_ballot_w64(L.pending);         // match of the previous probe (its commit is owed)
         uint64_t sl = 0;                                              // slide of the previous probe (none owed)
         uint32_t opn = op;                                            // ... committing it again changes nothing
@@ -1472,7 +1511,9 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
         if (have && !parked && waiting == 0u)
             snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
-                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu, T.lut_okey SNK_PROF_PASS);
+                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off,
+                                           EXC ? SNK_EXC_GATHER : 0xFFFFFFFFu,       // (EXC: lanes parked at a site are looked after at least this often)
+                                           T.lut_okey SNK_PROF_PASS);
     }
 }
 
