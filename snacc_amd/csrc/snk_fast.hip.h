@@ -1512,7 +1512,11 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         if (have && !parked && waiting == 0u)
             snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
                                            gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off,
-                                           EXC ? SNK_EXC_GATHER : 0xFFFFFFFFu,       // (EXC: lanes parked at a site are looked after at least this often)
+#if defined(SNK_PARK) && SNK_PARK == 1
+                                           EXC ? SNK_EXC_GATHER : 0xFFFFFFFFu,       // (lanes parked at a site are looked after at least this often)
+#else
+                                           0xFFFFFFFFu,
+#endif
                                            T.lut_okey SNK_PROF_PASS);
     }
 }
