@@ -37,6 +37,7 @@ struct snk_ctx_impl {
     uint32_t *d_far = nullptr; size_t far_bytes = 0;     // tables of the 2-bit kernel's far chains (one set per context)
     hipEvent_t far_busy = nullptr; bool far_in_flight = false;   // ... in use until the launch that got them ends
     int far_lanes = 0, far_waves = 4; // far_lanes 0 = no far chains
+    int far_min = 4;                 // far chains only in launches of at least far_min jobs per LDS chain of the card (0: always; tests)
     int far_stop_pct = 140;          // far waves take no new jobs once fewer than this % of (LDS chains of the launch) jobs are left
     hipEvent_t ovf_busy = nullptr;   // last 2-bit launch with exceptions: its chains' overflow tables (one set per context) are
     bool ovf_in_flight = false;      // in use until it ends -- the next such launch waits for it on its own stream
@@ -243,7 +244,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const bool dense = tile && tile->rows > 0;
         // far chains (tables in global memory, extra waves): pair launches of pure-ACGT sets that fill the card
         uint32_t far_waves = (!exc && !singles && c->far_lanes > 0) ? (uint32_t)c->far_waves : 0u;
-        if (far_waves && (waves + far_waves > 8u || n_fast < (size_t)4 * chains * (size_t)std::max(c->n_cus, 1))) far_waves = 0u;
+        if (far_waves && (waves + far_waves > 8u || n_fast < (size_t)c->far_min * chains * (size_t)std::max(c->n_cus, 1))) far_waves = 0u;
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
@@ -588,6 +589,9 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "far_waves") {
         if (value < 1 || value > 7) return fail(c, SNK_E_ARG, "far_waves must be 1..7");
         c->far_waves = (int)value;
+    } else if (k == "far_min") {
+        if (value < 0 || value > 1000) return fail(c, SNK_E_ARG, "far_min must be 0..1000");
+        c->far_min = (int)value;
     } else if (k == "far_stop_pct") {
         if (value < 0 || value > 10000) return fail(c, SNK_E_ARG, "far_stop_pct must be 0..10000");
         c->far_stop_pct = (int)value;
