@@ -1509,15 +1509,31 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 #endif
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave
-        if (have && !parked && waiting == 0u)
-            snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
-                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off,
+        uint32_t round = 0xFFFFFFFFu;
 #if defined(SNK_PARK) && SNK_PARK == 1
-                                           EXC ? SNK_EXC_GATHER : 0xFFFFFFFFu,       // (lanes parked at a site are looked after at least this often)
-#else
-                                           0xFFFFFFFFu,
+        if (EXC) round = SNK_EXC_GATHER;                       // (lanes parked at a site are looked after at least this often)
 #endif
-                                           T.lut_okey SNK_PROF_PASS);
+#if defined(SNK_BAND) && SNK_BAND > 0
+        // diagnostic build (sequences with exceptions): keep the wave's lanes that walk one suffix within SNK_BAND bases of the
+        // hindmost of them, so that they reach an exception site within a few trips of each other
+        if (EXC) {
+            const bool iny = have && L.cur >= L.s.lx + 4u;
+            const unsigned long long ym = __builtin_amdgcn_ballot_w64(iny);
+            if (ym) {
+                const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)L.s.yoff, (int)__builtin_ctzll(ym));
+                const bool same = iny && L.s.yoff == wy;
+                uint32_t yp = same ? L.cur - L.s.lx : 0xFFFFFFFFu;
+                for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)yp, o); yp = v < yp ? v : yp; }
+                if (same) {
+                    const uint32_t room = yp + (uint32_t)SNK_BAND - (L.cur - L.s.lx);      // bases this lane may still walk (>= SNK_BAND for the hindmost)
+                    round = (int32_t)room <= 0 ? 0u : (room < round ? room : round);
+                }
+            }
+        }
+#endif
+        if (have && !parked && waiting == 0u && round != 0u)
+            snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
+                                           gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, round, T.lut_okey SNK_PROF_PASS);
     }
 }
 
