@@ -822,6 +822,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 // blocks at the same place of y) are parked -- taken out of EXEC, registers frozen in the state every lane leaves the loop
 // in -- and the others walk on, instead of one wave exit and re-entry per lane.  Nothing is added to the trip itself.
 #ifdef SNK_PARK
+#define SNK_EC "&"
 #define SNK_STEADY_ENTER "s_mov_b64 %[se], exec\n\t"
 #define SNK_STEADY_PARK \
     "s_cmp_eq_u64 %[blk], 0\n\t"                       /* blk: the lanes whose limit may park them; 0 = none */ \
@@ -838,6 +839,7 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
     ".Lsnk_leave%=:\n\t" \
     "s_mov_b64 exec, %[se]\n\t"
 #else
+#define SNK_EC ""
 #define SNK_STEADY_ENTER
 #define SNK_STEADY_PARK
 #endif
@@ -883,10 +885,13 @@ __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)
 #define SNK_STEADY_OPERANDS SNK_STEADY_OPERANDS_X()
 #define SNK_STEADY_OPERANDS_FAR SNK_STEADY_OPERANDS_X(, [gtb] "v"(gtb), [ftab] "s"(ftab), [vbm2] "v"(vb - 2u), [k17] "s"(131071))
 #define SNK_STEADY_OPERANDS_X(...) \
-    /* ("+&": an input-only operand of equal value -- blk and sl both start as 0 -- must not share the register) */ \
-    : [c] "+&v"(c), [wc] "+&v"(wc), [s1] "+&v"(s1), [s2] "+&v"(s2), [r0] "+&v"(r0), [r1] "+&v"(r1), \
-      [rbc] "+&v"(rbc), [nxoff] "+&v"(nxoff), [anchor] "+&v"(anchor_c), [op] "+&v"(op), \
-      [opn] "+&v"(opn), [ns2] "+&v"(ns2), [sm] "+&s"(sm), [sl] "+&s"(sl), \
+    /* (SNK_EC: under -DSNK_PARK the read-write operands are early-clobber -- the input-only blk = 0 was otherwise given the */ \
+    /* register pair of sl = 0 and overwritten by the loop.  The shipped loop has no input-only operand of provably equal */ \
+    /* value and keeps the plain form: with early-clobber the register numbering changes and the loop runs 2 % slower, */ \
+    /* 448 k against 457 k pair-compr./s -- operand banks.) */ \
+    : [c] "+" SNK_EC "v"(c), [wc] "+" SNK_EC "v"(wc), [s1] "+" SNK_EC "v"(s1), [s2] "+" SNK_EC "v"(s2), [r0] "+" SNK_EC "v"(r0), [r1] "+" SNK_EC "v"(r1), \
+      [rbc] "+" SNK_EC "v"(rbc), [nxoff] "+" SNK_EC "v"(nxoff), [anchor] "+" SNK_EC "v"(anchor_c), [op] "+" SNK_EC "v"(op), \
+      [opn] "+" SNK_EC "v"(opn), [ns2] "+" SNK_EC "v"(ns2), [sm] "+" SNK_EC "s"(sm), [sl] "+" SNK_EC "s"(sl), \
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [se] "=&s"(se) \
     : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
       [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
