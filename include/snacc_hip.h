@@ -81,6 +81,11 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   4 + 1.25 * exc_limit such runs per 2^20 bases (default 4915: 60 % of the granules, 6148 runs per
  *                   Mbp); 0 = pure ACGT only.  Set before snk_upload.
  *   "fast_dynamic"  -1 auto / 0 static round robin / 1 atomic queue: how the waves of the 2-bit kernel take their batches
+ *   "far_lanes", "far_waves", "far_min", "far_stop_pct"  chains of the 2-bit kernel beyond the LDS (extra waves whose chains
+ *                   keep their tables in global memory; far_lanes 0 = none, the default).  A measured negative kept for
+ *                   reproduction (profiles/r03_far_chains.json): leave it off.  far_min: only launches of at least that many
+ *                   jobs per LDS chain of the card use them (default 4); far_stop_pct: far waves take no new jobs once fewer
+ *                   than this percentage of (LDS chains of the launch) jobs are left (default 140)
  *   "force_generic" 1 = route every pair through the byte kernel (testing)
  *   "deflate_serial" 1 = gzip / zlib: parse every single sequence with one wavefront from start to end
  *                   instead of in stitched parallel segments (testing; set before the first deflate call)
