@@ -574,7 +574,10 @@ def main():
                             else cpu_baseline_lz4(genomes, L, args.cpu_seconds))
     cli_run = None
     if rank == 0 and world == 1 and not args.no_cli_wall:
-        cli_run = cli_wall(genomes, args.codec, os.environ.get("TMPDIR", "/tmp"))
+        try:
+            cli_run = cli_wall(genomes, args.codec, os.environ.get("TMPDIR", "/tmp"))
+        except Exception as e:                              # noqa: BLE001  (an extra of the line: e.g. no room for the FASTA files)
+            cli_run = {"cli_wall_s": None, "error": repr(e)}
 
     if rank == 0:
         if args.mode == "strong" and matrix:
