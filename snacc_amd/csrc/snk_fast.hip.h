@@ -1317,6 +1317,10 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         bool need = lane_on && !have;
         while (!dry && __any(need)) {
             if (wb >= we) {
+                // (sequences with exceptions) the lanes of a wave serve each other at the sites of the suffix they share: a lane
+                // that has finished waits for the wave's batch to end instead of starting on the next batch's suffix alone
+                // (measured at 336 rows x 1024: 100 IUPAC codes per Mbp 62 -> 74 % of the pure rate, the rest unchanged)
+                if (EXC && __any(have)) break;
                 if (G.queue) {           // dynamic: the next jobs of the launch, as many as the wave has chains
                     const uint32_t want = FAR ? lanes : G.batch;
                     uint32_t b = 0xFFFFFFFFu;
