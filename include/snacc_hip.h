@@ -74,6 +74,10 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   (full table / compact 1024 slots / compact 2048 slots)
  *   "bytes_compact" -1 auto (default) / 0 never: compact table of the byte kernel when the
  *                   resident sequences use <= 2048 distinct 5-byte hashes (set before upload)
+ *   "bytes_gt"      byte kernels with their tables in global memory, one chain per lane: waves per workgroup (1..8);
+ *                   0 = tables in LDS; -1 (default) = 4 for the full table once the launch has more jobs than two rounds
+ *                   of the LDS kernel, LDS otherwise (the compact tables are faster in LDS).  "bytes_gt_wgs": workgroups
+ *                   per CU and launch (default 1; the host launches ceil(jobs / capacity) times, one table per chain)
  *   "bytes_legacy"  1 = linked-mode byte jobs use the legacy u32-table kernel (testing)
  *   "exc_limit"     a sequence with bytes other than ACGT (acgt in a set that is mostly lower case) -- N runs, IUPAC codes,
  *                   stretches in the other case -- stays on the 2-bit

@@ -184,7 +184,7 @@ __device__ __forceinline__ uint32_t snk_bslot_slow(const SnkByteSrc &s, uint32_t
     return SnkBT<CAP, ONESHOT>::SEAM0 + (uint32_t)(q - j0);
 }
 
-template <int CAP, bool ONESHOT>
+template <int CAP, bool ONESHOT, bool GT = false>     // GT: `tbl` is the chain's table in global memory (u32 absolute positions, see snk_bytes_gt_body)
 __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                      uint32_t *out, uint32_t *status)
 {
@@ -208,7 +208,8 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
                 const uint32_t t = snk_bslot<(CAP != 0)>(h);
                 uint32_t v = 0u;
                 if (CAP == 0 || t != SNK_BC_NOSLOT) {
-                    if ((bm[t >> 5] >> (t & 31u)) & 1u) v = L.pos - 65536u + tbl[t];
+                    if (GT) v = ((const uint32_t *)tbl)[t];              // the reader drops what is out of reach
+                    else if ((bm[t >> 5] >> (t & 31u)) & 1u) v = L.pos - 65536u + tbl[t];
                 }
                 dst[h] = v;
             }
@@ -219,7 +220,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.blen = L.n - L.pos < SNK_BLOCK ? L.n - L.pos : SNK_BLOCK;
         L.iend = L.pos + L.blen;
         if (L.blen < 13u) { L.total += 4u + L.blen; L.pos = L.iend; continue; }
-        if (!L.first) {
+        if (!GT && !L.first) {
             for (uint32_t wi = 0; wi < (SnkBT<CAP, ONESHOT>::SLOTS + 31u) / 32u; ++wi) {
                 uint32_t z = ~bm[wi];
                 while (z) {
@@ -235,8 +236,8 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         {
             const uint32_t s0 = snk_bslot_slow<CAP, ONESHOT>(L.s, L.pos);
-            tbl[s0] = 0;
-            atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
+            if (GT) ((uint32_t *)tbl)[s0] = L.pos;
+            else { tbl[s0] = 0; atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u)); }
         }
         L.cur = L.pos + 1u; L.step = 1u; L.nb = 64u; L.anchor = L.pos; L.op = 0u;
         L.pending = false; L.in_block = true;
@@ -275,11 +276,23 @@ __device__ __forceinline__ void snk_bytes_match_slow(SnkByteLane &L, uint32_t cu
 }
 
 // table probe shared by the slow and the tight paths: returns candidate + validity, performs the puts
-template <int CAP, bool ONESHOT>
+template <int CAP, bool ONESHOT, bool GT = false>
 __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *tbl, uint32_t *bm, uint32_t cur,
                                                 uint32_t s1, uint32_t s2, uint32_t &cand, bool &valid)
 {
     s2 = L.pending ? s2 : SnkBT<CAP, ONESHOT>::DUMMY;
+    if (GT) {
+        // liblz4's own table: absolute positions, a candidate counts while it is within 65535 bytes
+        uint32_t *const gt = (uint32_t *)tbl;
+        const uint32_t e = gt[s1];
+        if (L.pending) gt[s2] = cur - 2u;          // nothing owed: no store at all (the kernel is bound by its memory traffic)
+        gt[s1] = cur;
+        const bool same = (s2 == s1);
+        cand = same ? cur - 2u : e;
+        valid = cur - cand <= 65535u;
+        cand = valid ? cand : cur;
+        return;
+    }
     const uint32_t e = tbl[s1];
     const uint32_t bw = bm[s1 >> 5];
     const uint32_t c = cur - L.base;
@@ -298,18 +311,18 @@ __device__ __forceinline__ void snk_bytes_table(const SnkByteLane &L, uint16_t *
 }
 
 // One fully general probe with direct loads (stream start, seam, after long jumps).
-template <int CAP, bool ONESHOT>
+template <int CAP, bool ONESHOT, bool GT = false>
 __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                     uint32_t *out, uint32_t *status)
 {
     const uint32_t cur = L.cur, next = cur + L.step;
-    if (next > L.mfl1) return snk_bytes_block_step<CAP, ONESHOT>(L, T, tbl, bm, out, status);
+    if (next > L.mfl1) return snk_bytes_block_step<CAP, ONESHOT, GT>(L, T, tbl, bm, out, status);
     const uint64_t wc = snk_bld8(L.s, cur);
     const uint32_t s1 = snk_bslot_slow<CAP, ONESHOT>(L.s, cur);
     // the put of cur-2 is owed only after a match, which ends at least 5 positions into the block
     const uint32_t s2 = L.pending ? snk_bslot_slow<CAP, ONESHOT>(L.s, cur - 2u) : SnkBT<CAP, ONESHOT>::DUMMY;
     uint32_t cand; bool valid;
-    snk_bytes_table<CAP, ONESHOT>(L, tbl, bm, cur, s1, s2, cand, valid);
+    snk_bytes_table<CAP, ONESHOT, GT>(L, tbl, bm, cur, s1, s2, cand, valid);
     const uint32_t s3 = L.nb >> 6;
     const uint64_t wd = snk_bld8(L.s, cand);
     if (valid && (uint32_t)wc == (uint32_t)wd) {
@@ -421,7 +434,7 @@ __device__ __forceinline__ void snk_bytes_loop(SnkByteLane &L, const SnkTables &
 // the next cursor is known; both hit the L1 (the wave's chains walk the same suffix).  Cursors whose 12-byte window does
 // not lie inside one sequence (stream start, seam) go through the general probe, as before.
 struct __attribute__((packed)) SnkU64p { uint64_t v; };
-template <int CAP>
+template <int CAP, bool GT = false>
 __device__ __forceinline__ void snk_bytes_loop2(SnkByteLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
                                                 uint32_t *out, uint32_t *status)
 {
@@ -434,18 +447,24 @@ __device__ __forceinline__ void snk_bytes_loop2(SnkByteLane &L, const SnkTables 
             next = cur + L.step;
             const bool pre = (next > L.mfl1) | (cur > L.w.lim) | (cur < L.w.org + 4u);     // w: which source serves the cursor (soff, org, lim)
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
-            if (pre && snk_bytes_iter_slow<CAP, false>(L, T, tbl, bm, out, status)) return;
+            if (pre && snk_bytes_iter_slow<CAP, false, GT>(L, T, tbl, bm, out, status)) return;
         }
         // data of the first probe
         uint32_t so = L.w.soff + (cur - L.w.org);                                           // ASCII arena offset of the cursor
-        uint64_t sv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)so - 2u))->v;               // slots of cur-2 .. cur+1
+        // full table in global memory: the slot IS liblz4's hash, taken from the window (the kernel waits for memory, not
+        // for its ALU: the multiplications cost less than the slot stream's line per probe)
+        constexpr bool HS = GT && CAP == 0;
+        uint64_t sv = 0;
+        if (!HS) sv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)so - 2u))->v;               // slots of cur-2 .. cur+1
         const SNK_AS1 SnkU96 *wp = (const SNK_AS1 SnkU96 *)(arena + (size_t)so - 4u);
         SnkW12 w; w.a = wp->a; w.b = wp->b; w.c = wp->c;
         const uint32_t olim6 = L.olimit - 6u;
 
         for (;;) {
             uint32_t cand; bool valid;
-            snk_bytes_table<CAP, false>(L, tbl, bm, cur, (uint32_t)(sv >> 32) & 0xFFFFu, (uint32_t)sv & 0xFFFFu, cand, valid);
+            const uint32_t s1 = HS ? snk_hash5_parts(w.b << 24, __builtin_amdgcn_alignbit(w.c, w.b, 8)) : (uint32_t)(sv >> 32) & 0xFFFFu;
+            const uint32_t s2 = HS ? snk_hash5_parts((w.a << 8) & 0xFF000000u, __builtin_amdgcn_alignbit(w.b, w.a, 24)) : (uint32_t)sv & 0xFFFFu;
+            snk_bytes_table<CAP, false, GT>(L, tbl, bm, cur, s1, s2, cand, valid);
             const SnkW12 wd = snk_bfetch12(L.s, cand);
 
             const uint32_t x0 = w.a ^ wd.a, x1 = w.b ^ wd.b, x2 = w.c ^ wd.c;
@@ -463,7 +482,8 @@ __device__ __forceinline__ void snk_bytes_loop2(SnkByteLane &L, const SnkTables 
 
             // ---- the next probe's data: direct loads (in flight during the bookkeeping) ----
             const uint32_t nso = so + (ncur - cur);
-            const uint64_t nsv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)nso - 2u))->v;
+            uint64_t nsv = 0;
+            if (!HS) nsv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)nso - 2u))->v;
             const SNK_AS1 SnkU96 *nwp = (const SNK_AS1 SnkU96 *)(arena + (size_t)nso - 4u);
             SnkW12 nw; nw.a = nwp->a; nw.b = nwp->b; nw.c = nwp->c;
 
@@ -577,6 +597,101 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
     if (!ONESHOT && T.slots) snk_bytes_loop2<CAP>(L, T, tbl, bm, out, status);
     else                     snk_bytes_loop<CAP, ONESHOT>(L, T, tbl, bm, out, status);
+}
+
+
+// ---- byte kernel with the tables in global memory ("gt") ----------------------------------------------------------
+// The LDS holds 18 full tables (70 compact ones) per CU, and the byte loop waits for memory on every trip (its
+// candidate windows come from a 64 KiB history, twice the L1): with so few chains the CU idles.  This form keeps each
+// chain's table -- liblz4's own layout, u32 absolute positions indexed by hash (or renamed slot), no bitmap, no ageing
+// -- in global memory, so that every lane of every wave runs a chain (blockDim.x chains per workgroup): a trip costs
+// one more trip to memory, and the CU has 30 times the chains to hide it behind.  The slot stream (T.slots) is
+// required.  One launch runs at most `grid * blockDim.x` jobs (one table each in `gtab`); the host loops.
+template <int CAP> struct SnkGT {
+    static constexpr uint32_t NS = (SnkBT<CAP, false>::SLOTS + 1u + 15u) & ~15u;     // u32 entries per chain (incl. the dummy)
+};
+template <int CAP>
+__device__ __forceinline__ void snk_bytes_gt_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
+                                                  uint32_t *gtab, uint32_t *out, uint32_t *status)
+{
+    typedef SnkBT<CAP, false> G;
+    constexpr uint32_t NS = SnkGT<CAP>::NS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t c = blockIdx.x * blockDim.x + tid;
+    const bool active = c < n_jobs;
+    if (CAP != 0) {
+        const uint32_t *lsrc = (const uint32_t *)T.lut_h2c;
+        for (uint32_t t = tid; t < G::LUT_B / 4u; t += blockDim.x)
+            ((uint32_t *)snk_lds8)[t] = lsrc[t];
+        __syncthreads();
+    }
+    SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
+    if (active) job = jobs[c];
+    uint32_t *const wave_tab = gtab + (size_t)(c - lane) * NS;
+
+    for (uint32_t l = 0; l < 64u; ++l) {
+        const int a   = __shfl((int)active, (int)l);
+        const int xi  = __shfl(job.xi, (int)l);
+        const int snp = __shfl(job.snap, (int)l);
+        if (!a) continue;
+        uint32_t *dst = wave_tab + (size_t)l * NS;
+        const uint32_t spos = T.snap_pos[xi];
+        const bool use = (snp == 0) && (spos != 0u);
+        const uint32_t *src = T.snap_gen + (size_t)xi * 4096u;
+        if (CAP == 0) {
+            for (uint32_t t = lane; t < NS; t += 64u) dst[t] = (use && t < 4096u) ? src[t] : 0u;
+        } else {
+            for (uint32_t t = lane; t < NS; t += 64u) dst[t] = 0u;
+            if (use) {
+                __threadfence();                                  // the zero fill lands before the scatter
+                for (uint32_t h = lane; h < 4096u; h += 64u) {
+                    const uint32_t id = snk_bslot<true>(h);
+                    if (id != SNK_BC_NOSLOT) dst[id] = src[h];
+                }
+            }
+        }
+    }
+    __threadfence();                                              // the tables are written before any lane reads its own
+    if (!active) return;
+
+    uint16_t *tbl = (uint16_t *)(wave_tab + (size_t)lane * NS);
+    SnkByteLane L;
+    const uint32_t lx = T.len[job.xi];
+    const uint32_t ly = job.yi >= 0 ? T.len[job.yi] : 0u;
+    L.s.arena = (snk_g8 *)T.bytes_arena;
+    L.s.xoff = T.bytes_off[job.xi];
+    L.s.yoff = job.yi >= 0 ? T.bytes_off[job.yi] : 16u;
+    L.s.lx = lx;
+    L.n = lx + ly;
+    L.spos = T.snap_pos[job.xi];
+    L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;
+    if (job.snap == 0 && L.spos != 0u) { L.pos = L.spos; L.total = T.snap_out[job.xi]; }
+    else                               { L.pos = 0u;     L.total = L.n ? T.header_bytes : 7u; }
+    L.blocks_left = (L.n >> 16) + 4u;
+    L.iend = 0; L.blen = 0; L.first = true; L.in_block = false;
+    L.cur = 0; L.step = 1; L.nb = 64; L.anchor = 0; L.op = 0;
+    L.mfl1 = 0; L.mlimit = 0; L.olimit = 0; L.base = L.pos; L.endcode = 0;
+    L.pending = false;
+    L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
+    L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
+    snk_bytes_loop2<CAP, true>(L, T, tbl, nullptr, out, status);
+}
+
+__global__ void __launch_bounds__(512) snk_bytes_gt_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                                           uint32_t *gtab, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_gt_body<0>(T, jobs, n_jobs, gtab, out, status);
+}
+__global__ void __launch_bounds__(512) snk_bytes_gt1k_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                                             uint32_t *gtab, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_gt_body<1024>(T, jobs, n_jobs, gtab, out, status);
+}
+__global__ void __launch_bounds__(512) snk_bytes_gt2k_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                                             uint32_t *gtab, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_gt_body<2048>(T, jobs, n_jobs, gtab, out, status);
 }
 
 __global__ void snk_bytes_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,

@@ -79,6 +79,60 @@ def test_byte_kernel_on_everything(hip, oracle_mod):
     _check_all(hip, oracle_mod, seqs, force_generic=1, bytes_compact=0)
 
 
+def test_byte_kernels_with_tables_in_global_memory(hip, oracle_mod):
+    """bytes_gt: every lane of every wave runs a chain whose table (liblz4's own layout, u32 positions) lies in
+    global memory.  The same sets as the LDS forms -- ragged block edges, long matches, low complexity, seam
+    strings outside the compact set, raw blocks, protein -- full table and both compact capacities."""
+    o = oracle_mod
+    lens = [65537, 131072, 200001, 70000, 65535 + 65536, 65548, 196608]
+    seqs = [o.lcg_genome(11 + i, n) for i, n in enumerate(lens)]
+    rep = np.tile(o.lcg_genome(32, 5000), 40)
+    seqs += [np.tile(o.lcg_genome(31, 37), 3000), rep, o.lcg_mutant(rep, 5),
+             np.frombuffer(b"A" * 150000, dtype=np.uint8), np.frombuffer(b"AC" * 60000, dtype=np.uint8),
+             np.frombuffer(b"N" * 1000 + bytes(o.lcg_genome(77, 90000)) + b"n" * 3000, dtype=np.uint8),
+             np.frombuffer(bytes(o.lcg_genome(78, 66000)) + b"NNNN", dtype=np.uint8),
+             np.frombuffer(b"NNNN" + bytes(o.lcg_genome(79, 80000)), dtype=np.uint8)]
+    _check_all(hip, o, seqs, force_generic=1, bytes_gt=2)                       # compact, 1024 slots
+    _check_all(hip, o, seqs, force_generic=1, bytes_compact=0, bytes_gt=4)      # full table, hashes taken from the window
+    soft = [np.frombuffer(bytes(x[:40000]) + bytes(x[40000:]).lower(), dtype=np.uint8) for x in seqs[:6]]
+    with hip.HipContext(0, force_generic=1, bytes_gt=3) as ctx:                 # compact, 2048 slots (both cases)
+        ctx.upload(soft)
+        assert 1024 < ctx.num_compact_hashes <= 2048
+        p = ctx.pairs()
+    assert np.array_equal(p, np.array([[o.lz4f_size_pair(a, b) for b in soft] for a in soft], dtype=np.uint32))
+    rng = np.random.default_rng(7)
+    mixed = [o.lcg_genome(21, 150000), rng.integers(0, 256, 140000, dtype=np.uint8),
+             np.frombuffer(lcg_bytes(31, 90000, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8),
+             np.frombuffer(lcg_bytes(32, 70001, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8)]
+    _check_all(hip, o, mixed, bytes_gt=1)
+    _check_all(hip, o, mixed, bytes_gt=8, bytes_gt_wgs=2)
+
+
+def test_global_table_byte_kernel_is_the_default_for_large_full_table_launches(hip, oracle_mod):
+    """Protein sequences (full table): a launch with more jobs than two rounds of the LDS kernel takes the
+    global-table kernel by itself.  144 x 144 pairs at one workgroup of 64 chains per CU and launch = two
+    launches of the kernel; the whole matrix equals the LDS kernel's, a sample equals the oracle's sizes."""
+    o = oracle_mod
+    n = 144
+    seqs = [np.frombuffer(lcg_bytes(500 + i, 66000 + 37 * (i % 5), b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8) for i in range(n)]
+    with hip.HipContext(0, bytes_gt=0) as ctx:
+        ctx.upload(seqs)
+        lds = ctx.pairs()
+        ms_lds = ctx.last_pairs_ms()
+    with hip.HipContext(0) as ctx:
+        ctx.upload(seqs)
+        auto = ctx.pairs()
+        ms_auto = ctx.last_pairs_ms()
+    with hip.HipContext(0, bytes_gt=1) as ctx:
+        ctx.upload(seqs)
+        two = ctx.pairs()
+    assert np.array_equal(lds, auto) and np.array_equal(lds, two)
+    for i, j in [(0, 0), (0, 1), (1, 0), (n - 1, n - 1), (n - 1, 0), (77, 5), (5, 77), (100, 143)]:
+        assert int(auto[i, j]) == o.lz4f_size_pair(seqs[i], seqs[j])
+    print(f"144 x 144 protein pairs: LDS tables {ms_lds:.1f} ms, global tables {ms_auto:.1f} ms")
+    assert ms_auto < ms_lds
+
+
 def test_compact_byte_kernel_seam_strings(hip, oracle_mod):
     """Mostly-ACGT genomes with N runs: the byte kernel runs with its compact table (<= 1024 distinct
     5-byte hashes).  Sequence ends/starts are chosen so that the 5-byte strings spanning the x/y seam

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Dev aid (GPU box): HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and the kernel time of one byte-kernel launch.
+# Usage: tools/gpu_bytes_pmc.sh OUTDIR MODE N L ROWS [option=value ...]
+OUT=$1; shift
+export TMPDIR=/tmp
+mkdir -p "$OUT"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 200 rocprofv3 --pmc $c --output-format csv -d "$OUT/$c" -- python3 tools/gpu_bytes_prof.py "$@" > "$OUT/$c.log" 2>&1
+  echo "$c done" >> "$OUT/progress.log"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+d = sys.argv[1]
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{d}/{c}/**/*counter_collection.csv", recursive=True)
+    per = {}
+    for row in csv.DictReader(open(f[0])):
+        if row["Kernel_Name"].startswith("snk_bytes") and row["Counter_Name"] == c:
+            k = (row["Kernel_Name"][:32], row["Dispatch_Id"])
+            per[k] = per.get(k, 0.0) + float(row["Counter_Value"])
+    for k, v in per.items():
+        print(c, k, "KB", v, "-> bytes", v * 1024 * (2 if c == "FETCH_SIZE" else 1))
+    print(open(f"{d}/{c}.log").read().strip().splitlines()[-1])
+PY
