@@ -72,8 +72,9 @@ struct snk_ctx_impl {
     std::vector<uint8_t> has_exc;    // ... the latter
     bool any_exc = false;
     bool lower = false;              // the resident set's letters are acgt: its 2-bit sequences, LUTs and exceptions go by the lower case
-    long exc_limit = 4915;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (60 % of
-                                     // them at 4915) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload)
+    long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (25 % of
+                                     // them at 2048) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload); beyond that the
+                                     // byte kernels are faster (measured crossover: 27 % soft-masked, 2400 IUPAC sites per Mbp)
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
     uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr, *d_lut_okey = nullptr;
@@ -323,32 +324,39 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     if (gt_waves < 0)
         gt_waves = (!c->compact_ok && n_bytes >= 2u * (size_t)(c->bytes_lanes * c->bytes_waves) * (size_t)std::max(c->n_cus, 1)) ? 4 : 0;
     if (singles || c->bytes_legacy || (c->compact_ok && !c->d_slots)) gt_waves = 0;
-    if (n_bytes && gt_waves > 0) {
+    // (both kernels at once on two streams, sharing the jobs -- the global-table kernel needs no LDS -- was measured:
+    // 119-126 k pair-compr/s on the compact set against 132 k for the LDS kernel alone)
+    const size_t n_gt = gt_waves > 0 ? n_bytes : 0;
+    const size_t n_lds = n_bytes - n_gt;
+    if (n_gt) {
         // every lane runs a chain; one launch per `cap` jobs (one table each)
         const int capn = c->compact_ok ? c->compact_cap : 0;
         const uint32_t ns = capn == 2048 ? SnkGT<2048>::NS : capn == 1024 ? SnkGT<1024>::NS : SnkGT<0>::NS;
         const uint32_t threads = 64u * (uint32_t)gt_waves;
         const size_t cap = (size_t)std::max(c->n_cus, 1) * (size_t)c->bytes_gt_wgs * threads;
-        const size_t need = std::min(cap, n_bytes) * ns * sizeof(uint32_t);
+        const size_t need = std::min(cap, n_gt) * ns * sizeof(uint32_t);
         if (need > c->bgt_bytes) {
             if (c->bgt_in_flight) { HIPCHK(c, hipEventSynchronize(c->bgt_busy)); c->bgt_in_flight = false; }
             dfree(c->d_bgt); c->bgt_bytes = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_bgt, need));
             c->bgt_bytes = need;
         }
-        if (c->bgt_in_flight) HIPCHK(c, hipStreamWaitEvent(st, c->bgt_busy, 0));
-        const size_t lds = capn ? (size_t)SnkBT<1024, false>::LUT_B : 0;
-        for (size_t done = 0; done < n_bytes; done += cap) {
-            const uint32_t nj = (uint32_t)std::min(cap, n_bytes - done);
+        hipStream_t gst = st;
+        if (c->bgt_in_flight) HIPCHK(c, hipStreamWaitEvent(gst, c->bgt_busy, 0));
+        for (size_t done = 0; done < n_gt; done += cap) {
+            const uint32_t nj = (uint32_t)std::min(cap, n_gt - done);
             const uint32_t grid = (nj + threads - 1u) / threads;
-            const SnkJob *jb = d_jobs + n_fast + done;
-            if (capn == 2048)      hipLaunchKernelGGL(snk_bytes_gt2k_kernel, dim3(grid), dim3(threads), lds, st, T, jb, nj, c->d_bgt, d_out, c->d_status);
-            else if (capn == 1024) hipLaunchKernelGGL(snk_bytes_gt1k_kernel, dim3(grid), dim3(threads), lds, st, T, jb, nj, c->d_bgt, d_out, c->d_status);
-            else                   hipLaunchKernelGGL(snk_bytes_gt_kernel,   dim3(grid), dim3(threads), lds, st, T, jb, nj, c->d_bgt, d_out, c->d_status);
+            const SnkJob *jb = d_jobs + n_fast + n_lds + done;
+            if (capn == 2048)      hipLaunchKernelGGL(snk_bytes_gt2k_kernel, dim3(grid), dim3(threads), 0, gst, T, jb, nj, c->d_bgt, d_out, c->d_status);
+            else if (capn == 1024) hipLaunchKernelGGL(snk_bytes_gt1k_kernel, dim3(grid), dim3(threads), 0, gst, T, jb, nj, c->d_bgt, d_out, c->d_status);
+            else                   hipLaunchKernelGGL(snk_bytes_gt_kernel,   dim3(grid), dim3(threads), 0, gst, T, jb, nj, c->d_bgt, d_out, c->d_status);
             HIPCHK(c, hipGetLastError());
         }
-        HIPCHK(c, hipEventRecord(c->bgt_busy, st)); c->bgt_in_flight = true;
-    } else if (n_bytes && c->compact_ok) {
+        HIPCHK(c, hipEventRecord(c->bgt_busy, gst)); c->bgt_in_flight = true;
+    }
+    const size_t n_bytes_all = n_bytes;
+    n_bytes = n_lds;
+    if (n_bytes && c->compact_ok) {
         const bool big = c->compact_cap == 2048;
         const uint32_t lanes = (uint32_t)(big ? c->c2bytes_lanes : c->cbytes_lanes);
         const uint32_t waves = (uint32_t)(big ? c->c2bytes_waves : c->cbytes_waves);
@@ -386,6 +394,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                            T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());
     }
+    n_bytes = n_bytes_all;
     if (n_gen && !c->bytes_legacy) {
         // one-shot inputs (n <= 64 KiB): the tight-loop kernel in one-shot mode
         const bool cmp = c->oneshot_compact_ok;

@@ -42,6 +42,7 @@ struct SnkByteSrc {
     snk_g8 *arena;            // wave-uniform base of the ASCII arena
     uint32_t xoff, yoff;      // byte offsets of the two sequences
     uint32_t lx;
+    const uint16_t *glut;     // global-table kernels (no LDS at all): the hash -> slot LUT in global memory, for the slow paths
 };
 
 __device__ __forceinline__ uint32_t snk_hash5_parts(uint32_t a_lo, uint32_t a_hi)
@@ -166,13 +167,13 @@ __device__ __forceinline__ SnkBProbeData snk_bextract(const SnkBWin &w, uint32_t
 // Slot of the 5 bytes at stream position p, for the slow paths (direct loads, seam aware).  In compact
 // mode a hash outside the resident set can only belong to a string spanning the seam (p in
 // [lx-4, lx-1]); equal seam hashes share one private slot, as they would share liblz4's.
-template <int CAP, bool ONESHOT>
+template <int CAP, bool ONESHOT, bool GT = false>
 __device__ __forceinline__ uint32_t snk_bslot_slow(const SnkByteSrc &s, uint32_t p)
 {
     const uint64_t w0 = snk_bld8(s, p);
     const uint32_t h = ONESHOT ? snk_hash4_u32((uint32_t)w0) : snk_hash5_parts((uint32_t)w0 << 24, (uint32_t)(w0 >> 8));
     if (CAP == 0) return h;
-    const uint32_t id = snk_bslot<true>(h);
+    const uint32_t id = GT ? (uint32_t)s.glut[h] : snk_bslot<true>(h);
     if (__builtin_expect(id != SNK_BC_NOSLOT, 1)) return id;
     const int32_t j0 = (int32_t)s.lx - (int32_t)(SnkBT<CAP, ONESHOT>::KBYTES - 1u);   // first seam-spanning position
     int32_t q = j0 < 0 ? 0 : j0;
@@ -205,7 +206,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
             // prefix snapshot, always in liblz4's hash-indexed form (absolute positions, 0 = too far)
             uint32_t *dst = T.snap_gen + (size_t)L.xi * 4096u;
             for (uint32_t h = 0; h < 4096u; ++h) {        // (never taken in one-shot mode: no snapshots)
-                const uint32_t t = snk_bslot<(CAP != 0)>(h);
+                const uint32_t t = (GT && CAP != 0) ? (uint32_t)L.s.glut[h] : snk_bslot<(CAP != 0)>(h);
                 uint32_t v = 0u;
                 if (CAP == 0 || t != SNK_BC_NOSLOT) {
                     if (GT) v = ((const uint32_t *)tbl)[t];              // the reader drops what is out of reach
@@ -235,7 +236,7 @@ __device__ __forceinline__ bool snk_bytes_block_step(SnkByteLane &L, const SnkTa
         L.base = L.pos;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
         {
-            const uint32_t s0 = snk_bslot_slow<CAP, ONESHOT>(L.s, L.pos);
+            const uint32_t s0 = snk_bslot_slow<CAP, ONESHOT, GT>(L.s, L.pos);
             if (GT) ((uint32_t *)tbl)[s0] = L.pos;
             else { tbl[s0] = 0; atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u)); }
         }
@@ -318,9 +319,9 @@ __device__ __forceinline__ bool snk_bytes_iter_slow(SnkByteLane &L, const SnkTab
     const uint32_t cur = L.cur, next = cur + L.step;
     if (next > L.mfl1) return snk_bytes_block_step<CAP, ONESHOT, GT>(L, T, tbl, bm, out, status);
     const uint64_t wc = snk_bld8(L.s, cur);
-    const uint32_t s1 = snk_bslot_slow<CAP, ONESHOT>(L.s, cur);
+    const uint32_t s1 = snk_bslot_slow<CAP, ONESHOT, GT>(L.s, cur);
     // the put of cur-2 is owed only after a match, which ends at least 5 positions into the block
-    const uint32_t s2 = L.pending ? snk_bslot_slow<CAP, ONESHOT>(L.s, cur - 2u) : SnkBT<CAP, ONESHOT>::DUMMY;
+    const uint32_t s2 = L.pending ? snk_bslot_slow<CAP, ONESHOT, GT>(L.s, cur - 2u) : SnkBT<CAP, ONESHOT>::DUMMY;
     uint32_t cand; bool valid;
     snk_bytes_table<CAP, ONESHOT, GT>(L, tbl, bm, cur, s1, s2, cand, valid);
     const uint32_t s3 = L.nb >> 6;
@@ -581,7 +582,7 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.s.arena = (snk_g8 *)T.bytes_arena;
     L.s.xoff = T.bytes_off[job.xi];
     L.s.yoff = job.yi >= 0 ? T.bytes_off[job.yi] : 16u;       // zero region at the arena start
-    L.s.lx = lx;
+    L.s.lx = lx; L.s.glut = nullptr;
     L.n = lx + ly;
     L.spos = T.snap_pos[job.xi];
     L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;
@@ -605,8 +606,9 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
 // candidate windows come from a 64 KiB history, twice the L1): with so few chains the CU idles.  This form keeps each
 // chain's table -- liblz4's own layout, u32 absolute positions indexed by hash (or renamed slot), no bitmap, no ageing
 // -- in global memory, so that every lane of every wave runs a chain (blockDim.x chains per workgroup): a trip costs
-// one more trip to memory, and the CU has 30 times the chains to hide it behind.  The slot stream (T.slots) is
-// required.  One launch runs at most `grid * blockDim.x` jobs (one table each in `gtab`); the host loops.
+// one more trip to memory, and the CU has 30 times the chains to hide it behind.  The kernel uses no LDS at all (the
+// slow paths read the hash -> slot LUT from global memory), so its workgroups fit beside any other kernel's.  The compact forms
+// read the slot stream (T.slots); the full table takes liblz4's hashes from the window.  One launch runs at most `grid * blockDim.x` jobs (one table each in `gtab`); the host loops.
 template <int CAP> struct SnkGT {
     static constexpr uint32_t NS = (SnkBT<CAP, false>::SLOTS + 1u + 15u) & ~15u;     // u32 entries per chain (incl. the dummy)
 };
@@ -614,18 +616,10 @@ template <int CAP>
 __device__ __forceinline__ void snk_bytes_gt_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
                                                   uint32_t *gtab, uint32_t *out, uint32_t *status)
 {
-    typedef SnkBT<CAP, false> G;
     constexpr uint32_t NS = SnkGT<CAP>::NS;
-    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t c = blockIdx.x * blockDim.x + tid;
     const bool active = c < n_jobs;
-    if (CAP != 0) {
-        const uint32_t *lsrc = (const uint32_t *)T.lut_h2c;
-        for (uint32_t t = tid; t < G::LUT_B / 4u; t += blockDim.x)
-            ((uint32_t *)snk_lds8)[t] = lsrc[t];
-        __syncthreads();
-    }
     SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
     if (active) job = jobs[c];
     uint32_t *const wave_tab = gtab + (size_t)(c - lane) * NS;
@@ -646,7 +640,7 @@ __device__ __forceinline__ void snk_bytes_gt_body(const SnkTables &T, const SnkJ
             if (use) {
                 __threadfence();                                  // the zero fill lands before the scatter
                 for (uint32_t h = lane; h < 4096u; h += 64u) {
-                    const uint32_t id = snk_bslot<true>(h);
+                    const uint32_t id = T.lut_h2c[h];
                     if (id != SNK_BC_NOSLOT) dst[id] = src[h];
                 }
             }
@@ -663,6 +657,7 @@ __device__ __forceinline__ void snk_bytes_gt_body(const SnkTables &T, const SnkJ
     L.s.xoff = T.bytes_off[job.xi];
     L.s.yoff = job.yi >= 0 ? T.bytes_off[job.yi] : 16u;
     L.s.lx = lx;
+    L.s.glut = T.lut_h2c;
     L.n = lx + ly;
     L.spos = T.snap_pos[job.xi];
     L.xi = job.xi; L.snap = job.snap; L.out_idx = job.out_idx;

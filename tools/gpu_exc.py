@@ -1,5 +1,5 @@
 """Dev aid: rate of the pair kernel on 1 Mbp genomes with non-ACGT places against pure ACGT ones.
-Usage: gpu_exc.py N L ROWS"""
+Usage: gpu_exc.py N L ROWS [kind ...] [option=value ...]"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
@@ -32,8 +32,8 @@ def variant(kind):
         out.append(a)
     return out
 ref = None
-KINDS = [k for k in sys.argv[4:] if not k.startswith("exc_limit=")] or ["pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac100"]
-OPTS = {k.split("=")[0]: int(k.split("=")[1]) for k in sys.argv[4:] if k.startswith("exc_limit=")}
+KINDS = [k for k in sys.argv[4:] if "=" not in k] or ["pure", "n1x1000", "n10x100", "iupac20", "n10x100+iupac20", "iupac100"]
+OPTS = {k.split("=")[0]: int(k.split("=")[1]) for k in sys.argv[4:] if "=" in k}       # any context option, e.g. exc_limit=0 force_generic=1 bytes_gt=3
 for kind in KINDS:
     seqs = variant(kind)
     ctx = HipContext(0, **OPTS)
@@ -63,5 +63,5 @@ for kind in KINDS:
             print(f"   wave cycles {int(st[7]):,}: in the loop {st[13] / st[7]:.1%}, loop entries {int(st[14]):,}, per entry: outside {(st[7] - st[13]) / st[14]:,.0f} cycles"
                   f" (finish {st[24] / st[14]:,.0f}, general rounds {st[25] / st[14]:,.0f} in {st[26] / st[14]:.2f} rounds)"
                   f"; per round {st[25] / max(1, st[26]):,.0f} cycles, of which inside the probe {st[28] / max(1, st[26]):,.0f}; loop prologue {st[27] / st[14]:,.0f}, top of the outer loop {st[29] / st[14]:,.0f}")
-    print(f"{kind:18s} packed={ctx.num_packed}/{N} ms={best:.1f} pairs/s={rate:.0f} ({rate / ref * 100:.0f}% of pure) parity={ok}", flush=True)
+    print(f"{OPTS if OPTS else ''} {kind:18s} packed={ctx.num_packed}/{N} ms={best:.1f} pairs/s={rate:.0f} ({rate / ref * 100:.0f}% of pure) parity={ok}", flush=True)
     ctx.close()
