@@ -338,7 +338,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         if (need > c->bgt_bytes) {
             if (c->bgt_in_flight) { HIPCHK(c, hipEventSynchronize(c->bgt_busy)); c->bgt_in_flight = false; }
             dfree(c->d_bgt); c->bgt_bytes = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_bgt, need));
+            HIPCHK(c, hipMalloc((void **)&c->d_bgt, need));      // (fine-grained: the same rate; uncached: 20 % slower)
             c->bgt_bytes = need;
         }
         hipStream_t gst = st;

@@ -22,3 +22,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print(c, k, "KB", v, "-> bytes", v * 1024 * (2 if c == "FETCH_SIZE" else 1))
     print(open(f"{d}/{c}.log").read().strip().splitlines()[-1])
 PY
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 tools/gpu_bytes_prof.py "$@" > "$OUT/stats.log" 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+f = glob.glob(f"{sys.argv[1]}/stats/**/*kernel_stats.csv", recursive=True)
+for row in csv.DictReader(open(f[0])):
+    if row["Name"].startswith("snk_bytes"):
+        print("kernel_stats", row["Name"][:40], "calls", row["Calls"], "avg ns", row["AverageNs"], "total ns", row["TotalDurationNs"])
+PY
+grep "pair-compr" "$OUT/stats.log"

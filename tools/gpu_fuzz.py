@@ -78,7 +78,9 @@ def one(seed):
     exp_p = pairs_mt(seqs, 0, n, 16)
     bad = []
     for opts in ({}, {"fast_asm": 0}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
-                 {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2}):
+                 {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2},
+                 {"force_generic": 1, "bytes_gt": 2}, {"force_generic": 1, "bytes_compact": 0, "bytes_gt": 3},      # tables in global memory
+                 {"exc_limit": 16384}):                                                                             # dense exceptions stay on the 2-bit kernel
         with hip.HipContext(0, **opts) as ctx:
             ctx.upload(seqs)
             s, p = ctx.singles(), ctx.pairs()
