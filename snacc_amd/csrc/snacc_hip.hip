@@ -48,6 +48,7 @@ struct snk_ctx_impl {
 
     // options
     bool fast_asm = true;            // 0 = the C++ statement of the 2-bit kernel's steady loop (cross-checks)
+    bool fast_spec = false;          // 1 = pure-ACGT pair launches run with speculative partner lanes (snk_fast_steady_spec)
     int fast_lanes = 0, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;   // fast_lanes 0 = as many as the LDS holds
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
@@ -253,7 +254,8 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
-        const void *fk = exc ? (singles ? (const void *)snk_fastx_singles_kernel
+        const bool spec = c->fast_spec && !exc && !singles && far_waves == 0u && lanes <= 32u;
+        const void *fk = spec ? (const void *)snk_fast_spec_kernel : exc ? (singles ? (const void *)snk_fastx_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
                              : (singles ? (const void *)snk_fast_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel);
@@ -310,6 +312,8 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             hipLaunchKernelGGL(snk_fastx_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (singles)
             hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+        else if (spec)
+            hipLaunchKernelGGL(snk_fast_spec_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (c->fast_asm)
             hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
         else
@@ -641,6 +645,8 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "far_stop_pct") {
         if (value < 0 || value > 10000) return fail(c, SNK_E_ARG, "far_stop_pct must be 0..10000");
         c->far_stop_pct = (int)value;
+    } else if (k == "fast_spec") {
+        c->fast_spec = value != 0;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
     } else if (k == "exc_limit") {

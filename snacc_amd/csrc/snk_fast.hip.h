@@ -1199,6 +1199,139 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #endif
 }
 
+#ifndef SNK_HOST_EMU
+// ---- the steady loop with speculative partner lanes ("fast_spec") ---------------------------------------------------
+// A wave of the 2-bit kernel serves 21 chains with 64-lane instructions and is bound by its own instruction issue: 43
+// lanes of every instruction do nothing.  They cannot run more chains (LDS), but they can run the SAME chain ahead.  On
+// genome data two probes of three are followed by a probe exactly 5 bases on (the match of the 5-mer ends there), so here
+// every chain has two lanes, a DPP pair (2i, 2i+1): lane 2i ("role 0") is the chain, lane 2i+1 ("role 1") probes at cur + 5
+// in the same trip, as liblz4's immediate probe after a match would: owed put of cur + 3, no literals, no catch-up.  When
+// role 0's probe turns out to be a match that ends exactly there (and neither needs service) both probes count and the
+// chain's next cursor comes from role 1; otherwise role 1's work is dropped.  Exactness: role 1 READS the table with
+// everybody at the top of the trip -- role 0's put(cur-2) has been issued before, its put(cur) is patched in by a select
+// when the slots are equal -- and WRITES nothing until it is known to count: its two puts are issued at the top of the
+// next trip, before anything else (liblz4's order).  C++ only (compiler-scheduled); pure ACGT pairs only.
+__device__ __forceinline__ uint32_t snk_pair_swap(uint32_t v)          // the partner's value inside the lane pair (2i, 2i+1)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+#define SNK_PAIR_TAKE(v) do { const uint32_t sw_ = snk_pair_swap((uint32_t)(v)); if (R1) (v) = sw_; } while (0)
+
+__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm)
+{
+    const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
+    // role 1 takes the chain's state at the loop entry from role 0
+    uint32_t vb = L.base, lx = L.s.lx, xoff = L.s.xoff, yoff = L.s.yoff, mfl1 = L.mfl1, wlim = L.w.lim, olimit = L.olimit;
+    uint32_t cur0 = L.cur, anchor0 = L.anchor, op = L.op, pend0 = L.pending ? 1u : 0u, wrb = L.w.rb, wsoff = L.w.soff, worg = L.w.org;
+    SNK_PAIR_TAKE(vb); SNK_PAIR_TAKE(lx); SNK_PAIR_TAKE(xoff); SNK_PAIR_TAKE(yoff); SNK_PAIR_TAKE(mfl1); SNK_PAIR_TAKE(wlim);
+    SNK_PAIR_TAKE(olimit); SNK_PAIR_TAKE(cur0); SNK_PAIR_TAKE(anchor0); SNK_PAIR_TAKE(op); SNK_PAIR_TAKE(pend0);
+    SNK_PAIR_TAKE(wrb); SNK_PAIR_TAKE(wsoff); SNK_PAIR_TAKE(worg);
+
+    const int32_t T0 = (int32_t)(vb - 65536u);
+    const int32_t X0 = T0 - 4, Y0 = T0 - 4 - (int32_t)lx;
+    const uint32_t kx = (uint32_t)X0 & 3u;
+    const uint32_t xoffB = xoff + (uint32_t)(X0 >> 2), yoffB = yoff + (uint32_t)(Y0 >> 2);
+    const int32_t sx = (int32_t)lx - 11 - T0;
+    const uint32_t limw = wlim == 0xFFFFFFFFu ? wlim : wlim + 1u;
+    const uint32_t lim_abs = mfl1 < limw ? mfl1 : limw;
+    const uint32_t limc = lim_abs - vb;
+    const int32_t olimZ = (int32_t)olimit - (int32_t)SNK_FAST_ZONE + 10;
+    const uint32_t DUMMY = SNK_FSLOTS - 1u;
+
+    uint32_t c = cur0 - vb + (R1 ? 5u : 0u);                      // this lane's cursor
+    uint32_t anchor_c = R1 ? c : anchor0 - vb;                    // role 1 never has literals
+    // this lane's own reservoir, seated from the arena: c - rbc in [0, 16)
+    uint32_t rbc = wrb + 4u - vb;
+    uint32_t nxoff = wsoff + ((wrb + 32u - worg) >> 2);
+    { const uint32_t sl = (c - rbc) >> 4; rbc += 16u * sl; nxoff += 4u * sl; }
+    uint32_t r0 = snk_ld4g(arena + (size_t)(nxoff - 8u)), r1 = snk_ld4g(arena + (size_t)(nxoff - 4u)), r2 = 0u;
+    uint32_t wc = __builtin_amdgcn_alignbit(r1, r0, 2u * (c - rbc));
+    uint32_t s1 = lut0[(wc >> 8) & 1023u];
+    uint32_t s2 = (R1 || pend0) ? (uint32_t)lut0[(wc >> 4) & 1023u] : DUMMY;
+    uint32_t d1 = DUMMY, d2 = DUMMY, dc = 2u;                     // role 1: the puts of its probe of the last trip, if it counted
+    uint32_t t; bool valid;
+
+    for (;;) {
+        // ---- table, in liblz4's order for the chain: role 1's probe of the last trip (put, put), then role 0's (put, get, put);
+        //      role 1 only reads at its new cursor.  A lane that has nothing to write writes the unused slot.
+        tbl[d2] = (uint16_t)(dc - 2u); atomicOr(&bm[d2 >> 5], 1u << (d2 & 31u));
+        tbl[d1] = (uint16_t)dc;        atomicOr(&bm[d1 >> 5], 1u << (d1 & 31u));
+        const uint32_t b2 = R1 ? DUMMY : s2, b1 = R1 ? DUMMY : s1;
+        tbl[b2] = (uint16_t)(c - 2u);  atomicOr(&bm[b2 >> 5], 1u << (b2 & 31u));
+        const uint32_t bit1 = s1 & 31u;
+        const uint32_t e = tbl[s1];
+        const uint32_t bw = atomicOr(&bm[s1 >> 5], (R1 ? 0u : 1u) << bit1);
+        tbl[b1] = (uint16_t)c;
+        t = e + (((bw >> bit1) & 1u) << 16);
+        {   // role 1: role 0's put(cur) of this trip and its own owed put(cur-2) have not been written
+            const uint32_t ps1 = snk_pair_swap(s1);
+            t = (R1 && ps1 == s1) ? 65536u + c - 5u : t;
+            t = (R1 && s2 == s1) ? 65534u + c : t;
+        }
+        valid = t > c;
+
+        // ---- candidate window and the reservoir refill ----
+        const bool inx = (int32_t)t < sx;
+        const uint32_t tt = t + (inx ? kx : 0u);
+        const uint64_t v = snk_ld8g(arena + (size_t)((inx ? xoffB : yoffB) + (tt >> 2)));
+        r2 = snk_ld4g(arena + (size_t)nxoff);
+        const bool straddle = valid & ((uint32_t)((int32_t)t - sx) < 15u);
+        const uint32_t lit = c - anchor_c;
+        const uint32_t wd = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, 2u * (tt & 3u));
+
+        // ---- compare, this lane's next cursor ----
+        const uint32_t x = wc ^ wd;
+        const uint32_t r = snk_ffbl(x >> 8);
+        const bool m = valid & (r >= 8u);
+        const uint32_t e2 = c + (r >> 1);
+        const uint32_t ncur = m ? e2 : c + 1u;
+
+        // ---- this probe's accounting ----
+        const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;
+        uint32_t b = eq < lit ? eq : lit;
+        { const uint32_t cand = (uint32_t)(T0 + (int32_t)t); b = b < cand ? b : cand; }
+        const uint32_t opn = op + (lit - b) + 3u;
+        int32_t mx = (int32_t)(b + 11u) > (int32_t)lit ? (int32_t)(b + 11u) : (int32_t)lit;
+        { const int32_t z = (int32_t)op - olimZ + 14 + 3; mx = mx > z ? mx : z; }       // (+3: role 1's sequence may be added in this trip)
+        const bool svc = (mx >= 15) | (ncur >= limc) | straddle | (e2 >= 0x20000000u);
+
+        // ---- the pair decides: role 0 offers "matched, ends where role 1 probed, no service", role 1 "no service" ----
+        const bool offer = !svc & (R1 | (m & ((r >> 1) == 5u)));
+        const uint32_t pk = (ncur & 0x3FFFFFFFu) | (m ? 0x40000000u : 0u) | (offer ? 0x80000000u : 0u);
+        const uint32_t qk = snk_pair_swap(pk);
+        const bool com = offer & ((int32_t)qk < 0);               // role 1's probe counts (the same value in both lanes)
+        const uint32_t n0 = R1 ? qk : pk, n1 = R1 ? pk : qk;      // (ncur, m) of role 0 / of role 1
+        const uint32_t nn = com ? n1 : n0;
+        const uint32_t cp = nn & 0x3FFFFFFFu;                     // the chain's next cursor
+        const bool mp = (nn & 0x40000000u) != 0u;                 // ... after a match (put(cur-2) owed)
+
+        // one wave-uniform exit, decided by the chains (role 0)
+        if (__builtin_amdgcn_ballot_w64(svc & !R1) != 0ull) break;
+
+        // ---- commit ----
+        const bool m1 = (n1 & 0x40000000u) != 0u;
+        op = m ? opn : op; anchor_c = m ? ncur : anchor_c;                       // role 0's probe (role 1's own copies are not used)
+        if (com & m1) { op += 3u; anchor_c = n1 & 0x3FFFFFFFu; }                 // role 1's: token + offset, no literals
+        d1 = (R1 & com) ? s1 : DUMMY; d2 = (R1 & com) ? s2 : DUMMY; dc = c;
+        const uint32_t nc = cp + (R1 ? 5u : 0u);
+        const uint32_t no = nc - rbc;                                            // 0..31
+        const bool sl = no >= 16u;
+        const uint32_t lo = sl ? r1 : r0, hi = sl ? r2 : r1;
+        const uint32_t nwc = __builtin_amdgcn_alignbit(hi, lo, 2u * no);
+        const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
+        const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
+        r0 = lo; r1 = hi; rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
+        c = nc; wc = nwc; s1 = ns1; s2 = (R1 | mp) ? ns2 : DUMMY;
+        anchor_c = R1 ? nc : anchor_c;
+    }
+    if (R1) return;
+    // role 0: hand the chain over in the state "table operations of the probe at c done, match not evaluated"
+    L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
+    L.w.rb = 0x80000000u;
+    snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+}
+#endif
+
 // How job numbers map to ordered pairs, and how the waves of a launch share them.
 //   jobs != NULL : explicit list (mixed tiles, pair lists, the single-sequence pass).
 //   jobs == NULL : dense tile of the N x N matrix: job q is the pair (x = r0 + q % rows, y = q / rows),
@@ -1270,10 +1403,11 @@ __device__ __forceinline__ void snk_fast_lane_init(SnkFastLane &L, const SnkTabl
 // (SnkFastGrid::far_*): u32 absolute positions, 3584 B per chain, one dependent load and two fire-and-forget stores per
 // probe.  Same probe semantics, same job stream (dynamic queue), same code around the loop; the LDS waves are untouched.
 // Not for sequences with exceptions, not for the singles pass (EXC / snapshot dumps know the LDS layout only).
-template <bool ASM, bool EXC, bool FAR>
+template <bool ASM, bool EXC, bool FAR, bool SPEC = false>       // SPEC: chain i of the wave = the lane pair (2i, 2i+1), see snk_fast_steady_spec
 __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastGrid &G,
                                               uint32_t lanes, uint32_t *out, uint32_t *status)
 {
+    static_assert(!SPEC || (!ASM && !EXC && !FAR), "speculative partner lanes: the C++ loop for pure ACGT pairs");
 #ifndef SNK_HOST_EMU
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
 #endif
@@ -1286,9 +1420,10 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
     SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
-    const bool lane_on = lane < lanes;
+    const uint32_t cidx = SPEC ? lane >> 1 : lane;                // the chain of the wave this lane belongs to
+    const bool lane_on = SPEC ? (!(lane & 1u) && cidx < lanes) : lane < lanes;      // ... and runs (SPEC: the odd lane only inside the steady loop)
     // LDS waves: the chain's table at LDS address mine_off (dynamic LDS starts at 0).  FAR waves: at word far_idx * 896 of G.far_tab.
-    const uint32_t mine_off = FAR ? 0u : SNK_FLUT_B + (wave * lanes + (lane_on ? lane : 0u)) * SNK_FCHAIN_B;
+    const uint32_t mine_off = FAR ? 0u : SNK_FLUT_B + (wave * lanes + (cidx < lanes ? cidx : 0u)) * SNK_FCHAIN_B;
     uint8_t *const mine = snk_lds8 + mine_off;
     uint16_t *const tbl = (uint16_t *)mine;
     uint32_t *const bm = (uint32_t *)(mine + SNK_FSLOTS * 2u);
@@ -1349,7 +1484,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 const uint32_t l = (uint32_t)__builtin_ctzll(tm);
                 const int xi  = __shfl(job.xi, (int)l);
                 const int snp = __shfl(job.snap, (int)l);
-                uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + l) * SNK_FCHAIN_B;
+                uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + (SPEC ? l >> 1 : l)) * SNK_FCHAIN_B;
                 const uint32_t spos = T.snap_pos[xi];
                 const bool use = (snp == 0) && (spos != 0u);
                 const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
@@ -1540,6 +1675,13 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
             }
         }
 #endif
+#ifndef SNK_HOST_EMU
+        if (SPEC) {
+            const bool go = have && !parked;
+            const bool pgo = snk_pair_swap(go ? 1u : 0u) != 0u;                 // (every lane of the wave is active here)
+            if (go || ((lane & 1u) && pgo)) snk_fast_steady_spec(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, tbl, bm);
+        } else
+#endif
         if (have && !parked && waiting == 0u && round != 0u)
             snk_fast_steady<ASM, EXC, FAR>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena), tbl, bm,
                                            gt, (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, round, T.lut_okey SNK_PROF_PASS);
@@ -1574,6 +1716,16 @@ __global__ void __launch_bounds__(512) snk_fast_kernel(SnkTables T, SnkFastGrid 
 __global__ void __launch_bounds__(512) snk_fast_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<false, false>(T, G, lanes, out, status);
+}
+
+// ... with speculative partner lanes (option fast_spec = 1; snk_fast_steady_spec)
+__global__ void __launch_bounds__(512) snk_fast_spec_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    snk_fast_wave<false, false, false, true>(T, G, lanes, out, status);
 }
 
 // phase A: single sequences + prefix snapshots at upload (same code, own symbol so that profiles
