@@ -255,7 +255,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
         const bool spec = c->fast_spec && !exc && !singles && far_waves == 0u && lanes <= 32u;
-        const void *fk = spec ? (const void *)snk_fast_spec_kernel : exc ? (singles ? (const void *)snk_fastx_singles_kernel
+        const void *fk = spec ? (c->fast_asm ? (const void *)snk_fast_spec_kernel : (const void *)snk_fast_spec_cxx_kernel) : exc ? (singles ? (const void *)snk_fastx_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
                              : (singles ? (const void *)snk_fast_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel);
@@ -312,8 +312,10 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             hipLaunchKernelGGL(snk_fastx_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (singles)
             hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (spec)
+        else if (spec && c->fast_asm)
             hipLaunchKernelGGL(snk_fast_spec_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+        else if (spec)
+            hipLaunchKernelGGL(snk_fast_spec_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (c->fast_asm)
             hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
         else

@@ -1200,6 +1200,174 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 }
 
 #ifndef SNK_HOST_EMU
+// ---- the speculative loop as gfx950 code (snk_fast_steady_spec<true>) ----------------------------------------------
+// Same dataflow as the C++ statement below, scheduled like the loop above.  Differences from that statement, all exact:
+//  * role 1 reads the table with role 0 at the top; role 0's two puts of the same trip are patched into role 1's result by
+//    selects (partner's slots through one DPP move), as the owed put is for everybody;
+//  * role 1's two puts are issued at the END of the trip its probe counted in (after role 0's, liblz4's order), with dummy
+//    addresses when it did not count -- the number of LDS operations in flight is the same every trip (s_waitcnt counts);
+//  * "counts" (com) = role 0's next cursor equals role 1's cursor; role 0 withholds its next cursor (-1) when it is sure to
+//    need service, so com implies that role 0's probe is an ordinary 5-base match; a counted role-1 probe that needs service
+//    itself (limit, straddling candidate, 12 equal bases) ends the loop and is handed over in role 0's place;
+//  * the chain's accounting is committed one trip late, in the shadow of the candidate load (masks sm0 / scm / sc0).
+#define SNK_SPEC_TABLE \
+    "1:\n\t" \
+    "s_waitcnt lgkmcnt(5)\n\t"                          /* slot of cur (behind it: slot of cur-2, role 1's four put operations) */ \
+    "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
+    "ds_read_u16 v91, v90\n\t" \
+    "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t" \
+    "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t" \
+    "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
+    "v_cndmask_b32_e64 v99, v93, 0, %[r1m]\n\t"         /* role 1 only reads */ \
+    "ds_or_rtn_b32 v94, v92, v99 offset:1792\n\t" \
+    "v_add_u32_e32 v96, -2, %[c]\n\t" \
+    "v_add_u32_e32 v112, 1, %[c]\n\t" \
+    "s_waitcnt lgkmcnt(6)\n\t"                          /* slot of cur-2 */ \
+    "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot (role 1: always owed) */ \
+    "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
+    "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t" \
+    "v_lshl_or_b32 v100, %[s2], 16, %[s1]\n\t"          /* both slots, for the partner */ \
+    "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
+    "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
+    "s_andn2_b64 exec, exec, %[r1m]\n\t"                /* role 0: put(cur-2), put(cur) */ \
+    "ds_write_b16 v95, v96\n\t" \
+    "ds_or_b32 v97, v98 offset:1792\n\t" \
+    "ds_write_b16 v90, %[c]\n\t" \
+    "s_or_b64 exec, exec, %[r1m]\n\t" \
+    "v_mov_b32_dpp v101, v100 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_u32_e32 v102, 0xfffb, %[c]\n\t"              /* role 1: the partner's put(cur) = this cursor - 5 */ \
+    "v_add_u32_e32 v103, 0xfff9, %[c]\n\t"              /* ... its put(cur-2) */ \
+    "v_add_u32_e32 v127, 0xfffe, %[c]\n\t" \
+    "v_cmp_eq_u16_sdwa %[ss], %[s1], v101 src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
+    "v_cmp_eq_u16_sdwa %[st], %[s1], v101 src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
+    "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
+    "s_and_b64 %[ss], %[ss], %[r1m]\n\t" \
+    "s_and_b64 %[st], %[st], %[r1m]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_bfe_u32 %[t], v94, %[s1], 1\n\t" \
+    "v_lshl_add_u32 %[t], %[t], 16, v91\n\t" \
+    "v_cndmask_b32_e64 %[t], %[t], v103, %[ss]\n\t" \
+    "v_cndmask_b32_e64 %[t], %[t], v102, %[st]\n\t" \
+    "v_cndmask_b32_e32 %[t], %[t], v127, vcc\n\t"
+#define SNK_SPEC_SHADOW(PH) \
+    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
+    "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
+    "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
+    "global_load_dword v108, %[nxoff], %[arena]\n\t" \
+    "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t" \
+    "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm0]\n\t"        /* last trip: role 0's probe was a match */ \
+    "v_add_u32_e32 v109, 3, %[op]\n\t" \
+    "v_add_u32_e32 v110, -1, %[c]\n\t" \
+    "v_cndmask_b32_e64 %[op], %[op], v109, %[scm]\n\t"          /* ... role 1's counted and was one: token + offset */ \
+    "v_cndmask_b32_e64 %[anchor], %[anchor], v110, %[sc0]\n\t"  /* ... counted and was none: the anchor is its cursor */ \
+    "v_cndmask_b32_e64 %[anchor], %[anchor], %[c], %[sm]\n\t"   /* after a match (role 1: always) the anchor is the cursor */ \
+    "v_sub_u32_e32 %[lit], %[c], %[anchor]\n\t" \
+    "v_sub_u32_e32 v124, %[op], %[oz]\n\t" \
+    "v_cmp_gt_u32_e64 %[sv], %[t], %[c]\n\t" \
+    "v_and_b32_e32 v109, 3, " PH "\n\t" \
+    "v_lshlrev_b32_e32 v109, 1, v109\n\t" \
+    "v_add_u32_e32 v111, %[T0], %[t]\n\t" \
+    "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
+// (after the straddle test of the DUAL form) what is known before the compare: Y = the cursor role 1 probes at (role 0: cur+5),
+// never matched (-2) when it is at the limit; role 0 will need service for its literal run, the budget (sp) or a
+// back-extension of 4 (sb & the compare's low byte)
+#define SNK_SPEC_PRE(STRAD_OR) \
+    "v_add_u32_e32 v119, %[c], %[fivec]\n\t" \
+    "v_max_i32_e32 v122, %[lit], v124\n\t" \
+    "v_cmp_ge_u32_e64 %[st], v119, %[limc]\n\t" \
+    "v_cmp_lt_i32_e64 %[sp], 14, v122\n\t" \
+    "v_cmp_lt_u32_e64 %[sb], 3, %[lit]\n\t" \
+    "v_cndmask_b32_e64 v119, v119, -2, %[st]\n\t" \
+    "v_cmp_lt_u32_e32 vcc, 3, v111\n\t" \
+    "v_sub_u32_e32 v127, v112, %[five]\n\t"             /* role 0's cursor + 1 */ \
+    "v_add_u32_e32 v104, 2, v96\n\t"                    /* this lane's cursor (c becomes the next one) */ \
+    STRAD_OR \
+    "s_and_b64 %[sb], %[sb], vcc\n\t"
+#define SNK_SPEC_REST(LIM) \
+    "s_waitcnt vmcnt(1)\n\t" \
+    "v_alignbit_b32 v113, v107, v106, v109\n\t" \
+    "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
+    "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
+    "v_and_b32_e32 v123, 0xff, v113\n\t" \
+    "v_ffbl_b32_e32 v114, v114\n\t" \
+    "v_cmp_eq_u32_e32 vcc, 0, v123\n\t"                 /* the 4 bases before cur are equal too */ \
+    "v_and_b32_e32 v114, v114, v110\n\t" \
+    "v_cmp_lt_u32_e64 %[sq], 7, v114\n\t"               /* this lane's probe is a match */ \
+    "v_lshrrev_b32_e32 v115, 1, v114\n\t" \
+    "s_and_b64 vcc, vcc, %[sb]\n\t" \
+    "v_add_u32_e32 v115, v115, %[c]\n\t" \
+    "s_or_b64 vcc, vcc, %[sp]\n\t" \
+    "s_andn2_b64 vcc, vcc, %[r1m]\n\t"                  /* role 0 withholds its next cursor when it is sure to need service */ \
+    "v_cndmask_b32_e64 v115, v112, v115, %[sq]\n\t"     /* this lane's next cursor */ \
+    "v_cndmask_b32_e64 v117, v115, -1, vcc\n\t" \
+    "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t" \
+    "v_ffbh_u32_e32 v120, v120\n\t" \
+    "v_mov_b32_dpp v121, v117 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_cndmask_b32_e64 v122, v117, v121, %[r1m]\n\t"    /* role 0's next cursor, in both lanes */ \
+    "v_cndmask_b32_e64 v123, v121, v117, %[r1m]\n\t"    /* role 1's */ \
+    "v_cmp_eq_u32_e64 %[sc], v122, v119\n\t"            /* role 0's match ends where role 1 probed: both count */ \
+    "v_lshrrev_b32_e32 v120, 1, v120\n\t" \
+    "v_add_u32_e32 v118, 5, v127\n\t"                   /* role 1's cursor + 1 */ \
+    "v_cndmask_b32_e64 v122, v122, v123, %[sc]\n\t"     /* the chain's next cursor */ \
+    "v_add_u32_e32 %[c], v122, %[five]\n\t"             /* this lane's */ \
+    "v_sub_u32_e32 v116, %[c], %[rbc]\n\t" \
+    "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t" \
+    "v_lshlrev_b32_e32 v116, 1, v116\n\t" \
+    "v_cndmask_b32_e64 v118, v127, v118, %[sc]\n\t"     /* cursor + 1 of the last probe that counted */ \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t" \
+    "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t" \
+    "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t" \
+    "v_lshrrev_b32_e32 v117, 7, %[wc]\n\t" \
+    "v_and_b32_e32 v117, 0x7fe, v117\n\t" \
+    "ds_read_u16 %[s1], v117\n\t" \
+    "v_lshrrev_b32_e32 v121, 3, %[wc]\n\t" \
+    "v_and_b32_e32 v121, 0x7fe, v121\n\t" \
+    "ds_read_u16 %[ns2], v121\n\t" \
+    /* role 1's puts, if its probe counted (else the unused slot / no bit) */ \
+    "s_and_b64 %[ss], %[sc], %[r1m]\n\t" \
+    "v_cndmask_b32_e64 v100, %[dma], v95, %[ss]\n\t" \
+    "v_cndmask_b32_e64 v101, 0, v98, %[ss]\n\t" \
+    "v_cndmask_b32_e64 v102, %[dma], v90, %[ss]\n\t" \
+    "v_cndmask_b32_e64 v103, 0, v93, %[ss]\n\t" \
+    "ds_write_b16 v100, v96\n\t" \
+    "ds_or_b32 v97, v101 offset:1792\n\t" \
+    "ds_write_b16 v102, v104\n\t" \
+    "ds_or_b32 v92, v103 offset:1792\n\t" \
+    /* this probe's accounting; the masks of the next trip */ \
+    "v_cmp_ne_u32_e64 %[sm], v122, v118\n\t"            /* the last probe that counted was a match: put(cur-2) owed */ \
+    "v_min3_u32 v120, v120, %[lit], v111\n\t" \
+    "v_sub_u32_e32 v121, %[lit], v120\n\t" \
+    "v_add3_u32 %[opn], %[op], v121, 3\n\t" \
+    "v_add_u32_e32 v123, 11, v120\n\t" \
+    "v_max3_i32 v125, v123, %[lit], v124\n\t" \
+    "s_andn2_b64 %[sm0], %[sq], %[r1m]\n\t" \
+    "s_and_b64 %[scm], %[sc], %[sm]\n\t" \
+    "s_andn2_b64 %[sc0], %[sc], %[sm]\n\t" \
+    "s_andn2_b64 %[scm], %[scm], %[r1m]\n\t" \
+    "s_andn2_b64 %[sc0], %[sc0], %[r1m]\n\t" \
+    "s_or_b64 %[sm], %[sm], %[r1m]\n\t" \
+    "v_cmp_lt_i32_e32 vcc, 14, v125\n\t" \
+    "v_cmp_ge_u32_e64 %[st], v115, " LIM "\n\t" \
+    "s_orn2_b64 %[ss], %[sc], %[r1m]\n\t"               /* role 0, and role 1 when its probe counts */ \
+    "s_or_b64 vcc, vcc, %[st]\n\t" \
+    "s_and_b64 vcc, vcc, %[ss]\n\t" \
+    "s_cbranch_vccz 1b\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define SNK_SPEC_OPERANDS \
+    : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
+      [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
+      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [sm0] "+s"(sm0), [scm] "+s"(scm), [sc0] "+s"(sc0), \
+      [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sq] "=&s"(sq), [sp] "=&s"(sp), \
+      [sb] "=&s"(sb), [sc] "=&s"(sc) \
+    : [lb] "v"(lds_off), [dma] "v"(dma), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
+      [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(DUMMY), \
+      [k8] "s"(0x00800000u), [arena] "s"(arena), [r1m] "s"(r1m) \
+    : "memory", "vcc", "scc", \
+      "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+      "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
+      "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
 // ---- the steady loop with speculative partner lanes ("fast_spec") ---------------------------------------------------
 // A wave of the 2-bit kernel serves 21 chains with 64-lane instructions and is bound by its own instruction issue: 43
 // lanes of every instruction do nothing.  They cannot run more chains (LDS), but they can run the SAME chain ahead.  On
@@ -1210,14 +1378,16 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 // chain's next cursor comes from role 1; otherwise role 1's work is dropped.  Exactness: role 1 READS the table with
 // everybody at the top of the trip -- role 0's put(cur-2) has been issued before, its put(cur) is patched in by a select
 // when the slots are equal -- and WRITES nothing until it is known to count: its two puts are issued at the top of the
-// next trip, before anything else (liblz4's order).  C++ only (compiler-scheduled); pure ACGT pairs only.
+// next trip, before anything else (liblz4's order).  Pure ACGT pairs only.  ASM: the hand-scheduled form above.
 __device__ __forceinline__ uint32_t snk_pair_swap(uint32_t v)          // the partner's value inside the lane pair (2i, 2i+1)
 {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 #define SNK_PAIR_TAKE(v) do { const uint32_t sw_ = snk_pair_swap((uint32_t)(v)); if (R1) (v) = sw_; } while (0)
 
-__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm)
+template <bool ASM>
+__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm,
+                                                     uint32_t lds_off)
 {
     const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
     // role 1 takes the chain's state at the loop entry from role 0
@@ -1251,6 +1421,32 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     uint32_t d1 = DUMMY, d2 = DUMMY, dc = 2u;                     // role 1: the puts of its probe of the last trip, if it counted
     uint32_t t; bool valid;
 
+    if (ASM) {
+        const uint64_t r1m = __builtin_amdgcn_ballot_w64(R1);                   // role 1 among the lanes in the loop
+        const uint32_t five = R1 ? 5u : 0u, dma = lds_off + 2u * DUMMY;
+        const uint32_t oz = (uint32_t)(olimZ - 14 - 3);
+        uint32_t ns2 = lut0[(wc >> 4) & 1023u];
+        uint32_t opn = op, lit;
+        if (R1) op = 0u, opn = 0u;                                              // role 1 keeps no account
+        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, sm0 = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc;
+        if (__all(sx + 15 <= 0))
+            asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
+                         SNK_SPEC_OPERANDS);
+        else
+            asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW("v103") SNK_STEADY_STRADDLE
+                         SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST("v105") SNK_SPEC_OPERANDS);
+        // the loop leaves before the trip's probes are committed: c holds the next cursor, lit + anchor the current one
+        uint32_t ccur = R1 ? anchor_c : lit + anchor_c;
+        const uint32_t t1 = snk_pair_swap(t), c1 = snk_pair_swap(ccur);
+        if (R1) return;
+        if ((sc >> (threadIdx.x & 63u)) & 1ull) {      // role 1's probe counts: role 0's is an ordinary 5-base match; hand over role 1's
+            op = opn; anchor_c = c1; ccur = c1; t = t1;
+        }
+        L.cur = vb + ccur; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (ccur - anchor_c);
+        L.w.rb = 0x80000000u;
+        snk_fast_finish(L, vb + ccur, (uint32_t)(T0 + (int32_t)t), t > ccur);
+        return;
+    }
     for (;;) {
         // ---- table, in liblz4's order for the chain: role 1's probe of the last trip (put, put), then role 0's (put, get, put);
         //      role 1 only reads at its new cursor.  A lane that has nothing to write writes the unused slot.
@@ -1407,7 +1603,7 @@ template <bool ASM, bool EXC, bool FAR, bool SPEC = false>       // SPEC: chain 
 __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastGrid &G,
                                               uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    static_assert(!SPEC || (!ASM && !EXC && !FAR), "speculative partner lanes: the C++ loop for pure ACGT pairs");
+    static_assert(!SPEC || (!EXC && !FAR), "speculative partner lanes: pure ACGT pairs");
 #ifndef SNK_HOST_EMU
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
 #endif
@@ -1679,7 +1875,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         if (SPEC) {
             const bool go = have && !parked;
             const bool pgo = snk_pair_swap(go ? 1u : 0u) != 0u;                 // (every lane of the wave is active here)
-            if (go || ((lane & 1u) && pgo)) snk_fast_steady_spec(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, tbl, bm);
+            if (go || ((lane & 1u) && pgo)) snk_fast_steady_spec<ASM>(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, tbl, bm, mine_off);
         } else
 #endif
         if (have && !parked && waiting == 0u && round != 0u)
@@ -1720,6 +1916,15 @@ __global__ void __launch_bounds__(512) snk_fast_cxx_kernel(SnkTables T, SnkFastG
 
 // ... with speculative partner lanes (option fast_spec = 1; snk_fast_steady_spec)
 __global__ void __launch_bounds__(512) snk_fast_spec_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    snk_fast_wave<true, false, false, true>(T, G, lanes, out, status);
+}
+// ... the C++ statement of that loop (fast_spec = 1, fast_asm = 0)
+__global__ void __launch_bounds__(512) snk_fast_spec_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
     for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)

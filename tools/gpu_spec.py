@@ -15,7 +15,7 @@ small = [oracle.lcg_genome(11 + i, n) for i, n in enumerate(lens)]
 rep = np.tile(oracle.lcg_genome(32, 5000), 40)
 small += [rep, oracle.lcg_mutant(rep, 5), oracle.lcg_mutant(small[7], 3), np.tile(oracle.lcg_genome(31, 37), 3000)]
 exp = pairs_mt(small, 0, len(small), 16)
-for opts in ({"fast_spec": 1}, {"fast_spec": 1, "fast_lanes": 5, "fast_waves": 2}):
+for opts in ({"fast_spec": 1}, {"fast_spec": 1, "fast_lanes": 5, "fast_waves": 2}, {"fast_spec": 1, "fast_asm": 0}):
     with HipContext(0, **opts) as ctx:
         ctx.upload(small)
         p = ctx.pairs()
@@ -25,7 +25,8 @@ for opts in ({"fast_spec": 1}, {"fast_spec": 1, "fast_lanes": 5, "fast_waves": 2
         sys.exit(1)
 seqs = lcg_genomes_torch(N, L, 1, torch.device("cuda", 0))
 ref = None
-for name, opts in (("hand-scheduled", {}), ("C++ statement", {"fast_asm": 0}), ("speculative lanes (C++)", {"fast_spec": 1})):
+for name, opts in (("hand-scheduled", {}), ("C++ statement", {"fast_asm": 0}), ("speculative lanes (C++)", {"fast_spec": 1, "fast_asm": 0}),
+                   ("speculative lanes, hand-scheduled", {"fast_spec": 1})):
     with HipContext(0, **opts) as ctx:
         ctx.upload(seqs)
         ctx.pairs(0, 2)
@@ -35,4 +36,4 @@ for name, opts in (("hand-scheduled", {}), ("C++ statement", {"fast_asm": 0}), (
             best = min(best, ctx.last_pairs_ms())
     same = True if ref is None else bool(np.array_equal(p, ref))
     ref = p if ref is None else ref
-    print(f"{name:26s} ms={best:.1f} pair-compr/s={R * N / best * 1e3:.0f} equal={same}", flush=True)
+    print(f"{name:34s} ms={best:.1f} pair-compr/s={R * N / best * 1e3:.0f} equal={same}", flush=True)
