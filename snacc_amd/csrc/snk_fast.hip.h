@@ -1220,30 +1220,22 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
     "v_cndmask_b32_e64 v99, v93, 0, %[r1m]\n\t"         /* role 1 only reads */ \
     "ds_or_rtn_b32 v94, v92, v99 offset:1792\n\t" \
-    "v_add_u32_e32 v96, -2, %[c]\n\t" \
     "v_add_u32_e32 v112, 1, %[c]\n\t" \
     "s_waitcnt lgkmcnt(6)\n\t"                          /* slot of cur-2 */ \
     "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot (role 1: always owed) */ \
-    "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
-    "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t" \
-    "v_lshl_or_b32 v100, %[s2], 16, %[s1]\n\t"          /* both slots, for the partner */ \
-    "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
-    "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
-    "s_andn2_b64 exec, exec, %[r1m]\n\t"                /* role 0: put(cur-2), put(cur) */ \
-    "ds_write_b16 v95, v96\n\t" \
-    "ds_or_b32 v97, v98 offset:1792\n\t" \
-    "ds_write_b16 v90, %[c]\n\t" \
-    "s_or_b64 exec, exec, %[r1m]\n\t" \
-    "v_mov_b32_dpp v101, v100 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
     "v_add_u32_e32 v102, 0xfffb, %[c]\n\t"              /* role 1: the partner's put(cur) = this cursor - 5 */ \
     "v_add_u32_e32 v103, 0xfff9, %[c]\n\t"              /* ... its put(cur-2) */ \
+    "v_lshl_or_b32 v100, %[s2], 16, %[s1]\n\t"          /* both slots, for the partner */ \
     "v_add_u32_e32 v127, 0xfffe, %[c]\n\t" \
+    "v_add_u32_e32 v96, -2, %[c]\n\t" \
+    "v_mov_b32_dpp v101, v100 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
+    "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
     "v_cmp_eq_u16_sdwa %[ss], %[s1], v101 src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
     "v_cmp_eq_u16_sdwa %[st], %[s1], v101 src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
-    "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
     "s_and_b64 %[ss], %[ss], %[r1m]\n\t" \
     "s_and_b64 %[st], %[st], %[r1m]\n\t" \
-    "s_waitcnt lgkmcnt(3)\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
     "v_bfe_u32 %[t], v94, %[s1], 1\n\t" \
     "v_lshl_add_u32 %[t], %[t], 16, v91\n\t" \
     "v_cndmask_b32_e64 %[t], %[t], v103, %[ss]\n\t" \
@@ -1254,8 +1246,16 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
     "global_load_dword v108, %[nxoff], %[arena]\n\t" \
+    "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t"                       /* role 0: put(cur-2), put(cur) -- behind the read, patched in for role 1 */ \
+    "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
+    "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
+    "s_andn2_b64 exec, exec, %[r1m]\n\t" \
+    "ds_write_b16 v95, v96\n\t" \
+    "ds_or_b32 v97, v98 offset:1792\n\t" \
+    "ds_write_b16 v90, %[c]\n\t" \
+    "s_or_b64 exec, exec, %[r1m]\n\t" \
     "v_lshl_add_u32 %[rbc], v126, 2, %[rbc]\n\t" \
-    "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sm0]\n\t"        /* last trip: role 0's probe was a match */ \
+    "v_cndmask_b32_e64 %[op], %[op], %[opn], %[sq]\n\t"         /* last trip: this lane's probe was a match (role 1 keeps no account: its op only drifts) */ \
     "v_add_u32_e32 v109, 3, %[op]\n\t" \
     "v_add_u32_e32 v110, -1, %[c]\n\t" \
     "v_cndmask_b32_e64 %[op], %[op], v109, %[scm]\n\t"          /* ... role 1's counted and was one: token + offset */ \
@@ -1341,11 +1341,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_add3_u32 %[opn], %[op], v121, 3\n\t" \
     "v_add_u32_e32 v123, 11, v120\n\t" \
     "v_max3_i32 v125, v123, %[lit], v124\n\t" \
-    "s_andn2_b64 %[sm0], %[sq], %[r1m]\n\t" \
     "s_and_b64 %[scm], %[sc], %[sm]\n\t" \
     "s_andn2_b64 %[sc0], %[sc], %[sm]\n\t" \
-    "s_andn2_b64 %[scm], %[scm], %[r1m]\n\t" \
-    "s_andn2_b64 %[sc0], %[sc0], %[r1m]\n\t" \
     "s_or_b64 %[sm], %[sm], %[r1m]\n\t" \
     "v_cmp_lt_i32_e32 vcc, 14, v125\n\t" \
     "v_cmp_ge_u32_e64 %[st], v115, " LIM "\n\t" \
