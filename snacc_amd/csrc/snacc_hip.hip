@@ -48,7 +48,7 @@ struct snk_ctx_impl {
 
     // options
     bool fast_asm = true;            // 0 = the C++ statement of the 2-bit kernel's steady loop (cross-checks)
-    bool fast_spec = false;          // 1 = pure-ACGT pair launches run with speculative partner lanes (snk_fast_steady_spec)
+    bool fast_spec = true;           // pure-ACGT pair launches run with two lanes per chain (snk_fast_steady_spec); 0 = one lane
     int fast_lanes = 0, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;   // fast_lanes 0 = as many as the LDS holds
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
@@ -255,10 +255,10 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
         const bool spec = c->fast_spec && !exc && !singles && far_waves == 0u && lanes <= 32u;
-        const void *fk = spec ? (c->fast_asm ? (const void *)snk_fast_spec_kernel : (const void *)snk_fast_spec_cxx_kernel) : exc ? (singles ? (const void *)snk_fastx_singles_kernel
+        const void *fk = spec ? (c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_spec_cxx_kernel) : exc ? (singles ? (const void *)snk_fastx_singles_kernel
                                         : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
                              : (singles ? (const void *)snk_fast_singles_kernel
-                                        : c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_cxx_kernel);
+                                        : c->fast_asm ? (const void *)snk_fast_one_kernel : (const void *)snk_fast_cxx_kernel);
         HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {   // the kernel addresses its slot LUT at LDS offset 0: that holds only without static LDS
             hipFuncAttributes fa;
@@ -313,11 +313,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         else if (singles)
             hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (spec && c->fast_asm)
-            hipLaunchKernelGGL(snk_fast_spec_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (spec)
             hipLaunchKernelGGL(snk_fast_spec_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
         else if (c->fast_asm)
-            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
+            hipLaunchKernelGGL(snk_fast_one_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
         else
             hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
         HIPCHK(c, hipGetLastError());

@@ -1384,8 +1384,11 @@ __device__ __forceinline__ uint32_t snk_pair_swap(uint32_t v)          // the pa
 
 template <bool ASM>
 __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm,
-                                                     uint32_t lds_off)
+                                                     uint32_t lds_off SNK_PROF_ARG)
 {
+#ifdef SNK_STATS
+    const unsigned long long stat_te = clock64();
+#endif
     const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
     // role 1 takes the chain's state at the loop entry from role 0
     uint32_t vb = L.base, lx = L.s.lx, xoff = L.s.xoff, yoff = L.s.yoff, mfl1 = L.mfl1, wlim = L.w.lim, olimit = L.olimit;
@@ -1418,6 +1421,10 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     uint32_t d1 = DUMMY, d2 = DUMMY, dc = 2u;                     // role 1: the puts of its probe of the last trip, if it counted
     uint32_t t; bool valid;
 
+#ifdef SNK_STATS
+    const unsigned long long stat_t0 = clock64();
+    P.prologue += stat_t0 - stat_te;
+#endif
     if (ASM) {
         const uint64_t r1m = __builtin_amdgcn_ballot_w64(R1);                   // role 1 among the lanes in the loop
         const uint32_t five = R1 ? 5u : 0u, dma = lds_off + 2u * DUMMY;
@@ -1432,6 +1439,10 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         else
             asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW("v103") SNK_STEADY_STRADDLE
                          SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST("v105") SNK_SPEC_OPERANDS);
+#ifdef SNK_STATS
+        const unsigned long long stat_t1 = clock64();
+        P.loop += stat_t1 - stat_t0; P.entries++;
+#endif
         // the loop leaves before the trip's probes are committed: c holds the next cursor, lit + anchor the current one
         uint32_t ccur = R1 ? anchor_c : lit + anchor_c;
         const uint32_t t1 = snk_pair_swap(t), c1 = snk_pair_swap(ccur);
@@ -1442,6 +1453,9 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         L.cur = vb + ccur; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (ccur - anchor_c);
         L.w.rb = 0x80000000u;
         snk_fast_finish(L, vb + ccur, (uint32_t)(T0 + (int32_t)t), t > ccur);
+#ifdef SNK_STATS
+        P.finish += clock64() - stat_t1;
+#endif
         return;
     }
     for (;;) {
@@ -1872,7 +1886,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         if (SPEC) {
             const bool go = have && !parked;
             const bool pgo = snk_pair_swap(go ? 1u : 0u) != 0u;                 // (every lane of the wave is active here)
-            if (go || ((lane & 1u) && pgo)) snk_fast_steady_spec<ASM>(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, tbl, bm, mine_off);
+            if (go || ((lane & 1u) && pgo)) snk_fast_steady_spec<ASM>(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, tbl, bm, mine_off SNK_PROF_PASS);
         } else
 #endif
         if (have && !parked && waiting == 0u && round != 0u)
@@ -1898,8 +1912,8 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 }
 
 #ifndef SNK_HOST_EMU
-// phase B: ordered pairs (the dominant kernel of the bench)
-__global__ void __launch_bounds__(512) snk_fast_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+// phase B, one lane per chain (option fast_spec = 0; far chains)
+__global__ void __launch_bounds__(512) snk_fast_one_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
 }
@@ -1911,8 +1925,8 @@ __global__ void __launch_bounds__(512) snk_fast_cxx_kernel(SnkTables T, SnkFastG
     snk_fast_kernel_body<false, false>(T, G, lanes, out, status);
 }
 
-// ... with speculative partner lanes (option fast_spec = 1; snk_fast_steady_spec)
-__global__ void __launch_bounds__(512) snk_fast_spec_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+// phase B: ordered pairs of pure ACGT sequences (the dominant kernel of the bench): two lanes per chain, snk_fast_steady_spec
+__global__ void __launch_bounds__(512) snk_fast_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
     for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)

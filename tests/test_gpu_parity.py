@@ -271,13 +271,15 @@ def test_hand_scheduled_steady_loop_equals_its_cxx_statement(hip, oracle_mod):
              np.repeat(rng.choice(acgt, 5000), rng.integers(1, 60, 5000))[:120000].copy()]
     exp_s = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
     exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
-    for asm in (1, 0):
-        with hip.HipContext(0, fast_asm=asm) as ctx:
+    # (round 3) ... and both exist in two forms: two lanes per chain (fast_spec=1, the default: the second lane probes 5 bases
+    # ahead in the same trip and counts when the first lane's match ends there) and one lane per chain (fast_spec=0)
+    for opts in ({}, {"fast_asm": 0}, {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0}, {"fast_lanes": 3, "fast_waves": 5}):
+        with hip.HipContext(0, **opts) as ctx:
             ctx.upload(seqs)
             assert ctx.num_packed == len(seqs)
             s, p = ctx.singles(), ctx.pairs()
-        assert np.array_equal(s, exp_s), (asm, np.flatnonzero(s != exp_s))
-        assert np.array_equal(p, exp_p), (asm, np.argwhere(p != exp_p)[:8].tolist())
+        assert np.array_equal(s, exp_s), (opts, np.flatnonzero(s != exp_s))
+        assert np.array_equal(p, exp_p), (opts, np.argwhere(p != exp_p)[:8].tolist())
 
 
 def _with_exceptions(rng, a, runs, singles):

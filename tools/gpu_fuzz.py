@@ -80,7 +80,7 @@ def one(seed):
     for opts in ({}, {"fast_asm": 0}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
                  {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2},
                  {"force_generic": 1, "bytes_gt": 2}, {"force_generic": 1, "bytes_compact": 0, "bytes_gt": 3},      # tables in global memory
-                 {"exc_limit": 16384}, {"fast_spec": 1}, {"fast_spec": 1, "fast_lanes": 7, "fast_waves": 2}):            # ... speculative partner lanes                                                                             # dense exceptions stay on the 2-bit kernel
+                 {"exc_limit": 16384}, {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0}):            # ... one lane per chain (the default has two)                                                                             # dense exceptions stay on the 2-bit kernel
         with hip.HipContext(0, **opts) as ctx:
             ctx.upload(seqs)
             s, p = ctx.singles(), ctx.pairs()

@@ -1,5 +1,5 @@
-"""Dev aid (GPU box): the 2-bit kernel with speculative partner lanes (fast_spec=1) against the hand-scheduled loop and its C++
-statement: parity on a small ragged set (every pair against the oracle), then rates on the bench shape.
+"""Dev aid (GPU box): the 2-bit kernel with two lanes per chain (fast_spec=1, the default) against the one-lane loop, both hand-scheduled
+and as their C++ statements: parity on a small ragged set (every pair against the oracle), then rates on the bench shape.
 Usage: gpu_spec.py N L ROWS"""
 import sys
 import numpy as np
@@ -15,7 +15,7 @@ small = [oracle.lcg_genome(11 + i, n) for i, n in enumerate(lens)]
 rep = np.tile(oracle.lcg_genome(32, 5000), 40)
 small += [rep, oracle.lcg_mutant(rep, 5), oracle.lcg_mutant(small[7], 3), np.tile(oracle.lcg_genome(31, 37), 3000)]
 exp = pairs_mt(small, 0, len(small), 16)
-for opts in ({"fast_spec": 1}, {"fast_spec": 1, "fast_lanes": 5, "fast_waves": 2}, {"fast_spec": 1, "fast_asm": 0}):
+for opts in ({}, {"fast_lanes": 5, "fast_waves": 2}, {"fast_asm": 0}, {"fast_spec": 0}):
     with HipContext(0, **opts) as ctx:
         ctx.upload(small)
         p = ctx.pairs()
@@ -25,8 +25,8 @@ for opts in ({"fast_spec": 1}, {"fast_spec": 1, "fast_lanes": 5, "fast_waves": 2
         sys.exit(1)
 seqs = lcg_genomes_torch(N, L, 1, torch.device("cuda", 0))
 ref = None
-for name, opts in (("hand-scheduled", {}), ("C++ statement", {"fast_asm": 0}), ("speculative lanes (C++)", {"fast_spec": 1, "fast_asm": 0}),
-                   ("speculative lanes, hand-scheduled", {"fast_spec": 1})):
+for name, opts in (("one lane, hand-scheduled", {"fast_spec": 0}), ("one lane, C++ statement", {"fast_spec": 0, "fast_asm": 0}),
+                   ("two lanes, C++ statement", {"fast_asm": 0}), ("two lanes, hand-scheduled (default)", {})):
     with HipContext(0, **opts) as ctx:
         ctx.upload(seqs)
         ctx.pairs(0, 2)
