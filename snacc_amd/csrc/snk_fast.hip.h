@@ -1269,8 +1269,9 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_add_u32_e32 v111, %[T0], %[t]\n\t" \
     "v_cndmask_b32_e64 v110, 0, -1, %[sv]\n\t"
 // (after the straddle test of the DUAL form) what is known before the compare: Y = the cursor role 1 probes at (role 0: cur+5),
-// never matched (-2) when it is at the limit; role 0 will need service for its literal run, the budget (sp) or a
-// back-extension of 4 (sb & the compare's low byte)
+// never matched (-2) when it is at the limit; role 0 will need service for its literal run, the budget (sp) or -- unless the
+// candidate lies within 4 bases of the stream start -- a back-extension of 4 (sb & the compare's low byte); a lane that
+// withholds its cursor leaves the loop in any case
 #define SNK_SPEC_PRE(STRAD_OR) \
     "v_add_u32_e32 v119, %[c], %[fivec]\n\t" \
     "v_max_i32_e32 v122, %[lit], v124\n\t" \
@@ -1278,28 +1279,25 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cmp_lt_i32_e64 %[sp], 14, v122\n\t" \
     "v_cmp_lt_u32_e64 %[sb], 3, %[lit]\n\t" \
     "v_cndmask_b32_e64 v119, v119, -2, %[st]\n\t" \
-    "v_cmp_lt_u32_e32 vcc, 3, v111\n\t" \
     "v_sub_u32_e32 v127, v112, %[five]\n\t"             /* role 0's cursor + 1 */ \
     "v_add_u32_e32 v104, 2, v96\n\t"                    /* this lane's cursor (c becomes the next one) */ \
-    STRAD_OR \
-    "s_and_b64 %[sb], %[sb], vcc\n\t"
+    STRAD_OR
 #define SNK_SPEC_REST(LIM) \
     "s_waitcnt vmcnt(1)\n\t" \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
     "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
-    "v_and_b32_e32 v123, 0xff, v113\n\t" \
+    "v_cmp_eq_u32_sdwa vcc, v113, %[vz] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   /* the 4 bases before cur are equal too */ \
     "v_ffbl_b32_e32 v114, v114\n\t" \
-    "v_cmp_eq_u32_e32 vcc, 0, v123\n\t"                 /* the 4 bases before cur are equal too */ \
     "v_and_b32_e32 v114, v114, v110\n\t" \
     "v_cmp_lt_u32_e64 %[sq], 7, v114\n\t"               /* this lane's probe is a match */ \
     "v_lshrrev_b32_e32 v115, 1, v114\n\t" \
     "s_and_b64 vcc, vcc, %[sb]\n\t" \
     "v_add_u32_e32 v115, v115, %[c]\n\t" \
-    "s_or_b64 vcc, vcc, %[sp]\n\t" \
-    "s_andn2_b64 vcc, vcc, %[r1m]\n\t"                  /* role 0 withholds its next cursor when it is sure to need service */ \
+    "s_or_b64 %[sp], vcc, %[sp]\n\t" \
+    "s_andn2_b64 %[sp], %[sp], %[r1m]\n\t"              /* role 0 withholds its next cursor when it is (all but) sure to need service */ \
     "v_cndmask_b32_e64 v115, v112, v115, %[sq]\n\t"     /* this lane's next cursor */ \
-    "v_cndmask_b32_e64 v117, v115, -1, vcc\n\t" \
+    "v_cndmask_b32_e64 v117, v115, -1, %[sp]\n\t" \
     "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t" \
     "v_ffbh_u32_e32 v120, v120\n\t" \
     "v_mov_b32_dpp v121, v117 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -1348,6 +1346,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cmp_ge_u32_e64 %[st], v115, " LIM "\n\t" \
     "s_orn2_b64 %[ss], %[sc], %[r1m]\n\t"               /* role 0, and role 1 when its probe counts */ \
     "s_or_b64 vcc, vcc, %[st]\n\t" \
+    "s_or_b64 vcc, vcc, %[sp]\n\t" \
     "s_and_b64 vcc, vcc, %[ss]\n\t" \
     "s_cbranch_vccz 1b\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t"
@@ -1359,7 +1358,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
       [sb] "=&s"(sb), [sc] "=&s"(sc) \
     : [lb] "v"(lds_off), [dma] "v"(dma), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
       [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(DUMMY), \
-      [k8] "s"(0x00800000u), [arena] "s"(arena), [r1m] "s"(r1m) \
+      [k8] "s"(0x00800000u), [arena] "s"(arena), [r1m] "s"(r1m), [vz] "v"(0u) \
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
