@@ -1204,24 +1204,41 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 // Same dataflow as the C++ statement below, scheduled like the loop above.  Differences from that statement, all exact:
 //  * role 1 reads the table with role 0 at the top; role 0's two puts of the same trip are patched into role 1's result by
 //    selects (partner's slots through one DPP move), as the owed put is for everybody;
-//  * role 1's two puts are issued at the END of the trip its probe counted in (after role 0's, liblz4's order), with dummy
-//    addresses when it did not count -- the number of LDS operations in flight is the same every trip (s_waitcnt counts);
+//  * role 1's two puts are issued in the trip its probe counted in, as soon as that is known (after role 0's, liblz4's
+//    order), with dummy addresses when it did not count;
 //  * "counts" (com) = role 0's next cursor equals role 1's cursor; role 0 withholds its next cursor (-1) when it is sure to
 //    need service, so com implies that role 0's probe is an ordinary 5-base match; a counted role-1 probe that needs service
 //    itself (limit, straddling candidate, 12 equal bases) ends the loop and is handed over in role 0's place;
-//  * the chain's accounting is committed one trip late, in the shadow of the candidate load (masks sm0 / scm / sc0).
+//  * the chain's accounting is committed one trip late, in the shadow of the candidate load (masks sq / scm / sc0).
+#define SNK_SPEC_DEF_X(VAL) \
+    "s_and_b64 %[ss], %[sc], %[r1m]\n\t"                /* role 1's puts, if its probe counted (else the unused slot / no bit) */ \
+    "v_cndmask_b32_e64 v100, %[dma], v95, %[ss]\n\t" \
+    "v_cndmask_b32_e64 v101, 0, v98, %[ss]\n\t" \
+    "v_cndmask_b32_e64 v102, %[dma], v90, %[ss]\n\t" \
+    "v_cndmask_b32_e64 v103, 0, v93, %[ss]\n\t" \
+    "ds_write_b16 v100, v96\n\t" \
+    "ds_or_b32 v97, v101 offset:1792\n\t" \
+    "ds_write_b16 v102, " VAL "\n\t" \
+    "ds_or_b32 v92, v103 offset:1792\n\t"
+// (measured the same within the noise between boxes, ~0.5 %: these puts before the cursor update instead -- one instruction
+// fewer -- and one or two waits for the two slots at the top)
+#define SNK_SPEC_DEF_A
+#define SNK_SPEC_DEF_B SNK_SPEC_DEF_X("v104")
+#define SNK_SPEC_W0 "4"
+#define SNK_SPEC_W1
+#define SNK_SPEC_CUR "v_add_u32_e32 v104, 2, v96\n\t"
 #define SNK_SPEC_TABLE \
     "1:\n\t" \
-    "s_waitcnt lgkmcnt(5)\n\t"                          /* slot of cur (behind it: slot of cur-2, role 1's four put operations) */ \
+    "s_waitcnt lgkmcnt(" SNK_SPEC_W0 ")\n\t"            /* the slots of cur and cur-2 (behind them: role 1's four put operations) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
     "ds_read_u16 v91, v90\n\t" \
     "v_lshrrev_b32_e32 v92, 5, %[s1]\n\t" \
     "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
     "v_cndmask_b32_e64 v99, v93, 0, %[r1m]\n\t"         /* role 1 only reads */ \
-    "ds_or_rtn_b32 v94, v92, v99 offset:1792\n\t" \
+    "ds_or_rtn_b32 v94, v92, v99 offset:1792\n\t" SNK_PADA \
     "v_add_u32_e32 v112, 1, %[c]\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t"                          /* slot of cur-2 */ \
+    SNK_SPEC_W1 \
     "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot (role 1: always owed) */ \
     "v_add_u32_e32 v102, 0xfffb, %[c]\n\t"              /* role 1: the partner's put(cur) = this cursor - 5 */ \
     "v_add_u32_e32 v103, 0xfff9, %[c]\n\t"              /* ... its put(cur-2) */ \
@@ -1240,12 +1257,12 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_lshl_add_u32 %[t], %[t], 16, v91\n\t" \
     "v_cndmask_b32_e64 %[t], %[t], v103, %[ss]\n\t" \
     "v_cndmask_b32_e64 %[t], %[t], v102, %[st]\n\t" \
-    "v_cndmask_b32_e32 %[t], %[t], v127, vcc\n\t"
+    "v_cndmask_b32_e32 %[t], %[t], v127, vcc\n\t" SNK_PADB
 #define SNK_SPEC_SHADOW(PH) \
     "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
-    "global_load_dword v108, %[nxoff], %[arena]\n\t" \
+    "global_load_dword v108, %[nxoff], %[arena]\n\t" SNK_PADC \
     "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t"                       /* role 0: put(cur-2), put(cur) -- behind the read, patched in for role 1 */ \
     "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
@@ -1280,10 +1297,10 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cmp_lt_u32_e64 %[sb], 3, %[lit]\n\t" \
     "v_cndmask_b32_e64 v119, v119, -2, %[st]\n\t" \
     "v_sub_u32_e32 v127, v112, %[five]\n\t"             /* role 0's cursor + 1 */ \
-    "v_add_u32_e32 v104, 2, v96\n\t"                    /* this lane's cursor (c becomes the next one) */ \
+    SNK_SPEC_CUR \
     STRAD_OR
 #define SNK_SPEC_REST(LIM) \
-    "s_waitcnt vmcnt(1)\n\t" \
+    "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
     "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
@@ -1306,6 +1323,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cmp_eq_u32_e64 %[sc], v122, v119\n\t"            /* role 0's match ends where role 1 probed: both count */ \
     "v_lshrrev_b32_e32 v120, 1, v120\n\t" \
     "v_add_u32_e32 v118, 5, v127\n\t"                   /* role 1's cursor + 1 */ \
+    SNK_SPEC_DEF_A \
     "v_cndmask_b32_e64 v122, v122, v123, %[sc]\n\t"     /* the chain's next cursor */ \
     "v_add_u32_e32 %[c], v122, %[five]\n\t"             /* this lane's */ \
     "v_sub_u32_e32 v116, %[c], %[rbc]\n\t" \
@@ -1321,27 +1339,18 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "ds_read_u16 %[s1], v117\n\t" \
     "v_lshrrev_b32_e32 v121, 3, %[wc]\n\t" \
     "v_and_b32_e32 v121, 0x7fe, v121\n\t" \
-    "ds_read_u16 %[ns2], v121\n\t" \
-    /* role 1's puts, if its probe counted (else the unused slot / no bit) */ \
-    "s_and_b64 %[ss], %[sc], %[r1m]\n\t" \
-    "v_cndmask_b32_e64 v100, %[dma], v95, %[ss]\n\t" \
-    "v_cndmask_b32_e64 v101, 0, v98, %[ss]\n\t" \
-    "v_cndmask_b32_e64 v102, %[dma], v90, %[ss]\n\t" \
-    "v_cndmask_b32_e64 v103, 0, v93, %[ss]\n\t" \
-    "ds_write_b16 v100, v96\n\t" \
-    "ds_or_b32 v97, v101 offset:1792\n\t" \
-    "ds_write_b16 v102, v104\n\t" \
-    "ds_or_b32 v92, v103 offset:1792\n\t" \
+    "ds_read_u16 %[ns2], v121\n\t" SNK_PADE \
+    SNK_SPEC_DEF_B \
     /* this probe's accounting; the masks of the next trip */ \
     "v_cmp_ne_u32_e64 %[sm], v122, v118\n\t"            /* the last probe that counted was a match: put(cur-2) owed */ \
     "v_min3_u32 v120, v120, %[lit], v111\n\t" \
     "v_sub_u32_e32 v121, %[lit], v120\n\t" \
-    "v_add3_u32 %[opn], %[op], v121, 3\n\t" \
-    "v_add_u32_e32 v123, 11, v120\n\t" \
-    "v_max3_i32 v125, v123, %[lit], v124\n\t" \
     "s_and_b64 %[scm], %[sc], %[sm]\n\t" \
     "s_andn2_b64 %[sc0], %[sc], %[sm]\n\t" \
     "s_or_b64 %[sm], %[sm], %[r1m]\n\t" \
+    "v_add3_u32 %[opn], %[op], v121, 3\n\t" \
+    "v_add_u32_e32 v123, 11, v120\n\t" \
+    "v_max3_i32 v125, v123, %[lit], v124\n\t" \
     "v_cmp_lt_i32_e32 vcc, 14, v125\n\t" \
     "v_cmp_ge_u32_e64 %[st], v115, " LIM "\n\t" \
     "s_orn2_b64 %[ss], %[sc], %[r1m]\n\t"               /* role 0, and role 1 when its probe counts */ \
@@ -1353,7 +1362,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #define SNK_SPEC_OPERANDS \
     : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
       [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
-      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [sm0] "+s"(sm0), [scm] "+s"(scm), [sc0] "+s"(sc0), \
+      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), \
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sq] "=&s"(sq), [sp] "=&s"(sp), \
       [sb] "=&s"(sb), [sc] "=&s"(sc) \
     : [lb] "v"(lds_off), [dma] "v"(dma), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
@@ -1431,7 +1440,7 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         uint32_t opn = op, lit;
         if (R1) op = 0u, opn = 0u;                                              // role 1 keeps no account
-        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, sm0 = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc;
+        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc;
         if (__all(sx + 15 <= 0))
             asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
                          SNK_SPEC_OPERANDS);
