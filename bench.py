@@ -42,7 +42,7 @@ LCG_C = 1442695040888963407
 # chains the LDS of a CU holds, and a lone wave per SIMD issues one instruction per ~4.2 cycles (tools/gpu_lat.hip).
 # The issue-slot floor of a trip = (instructions per wave-trip, from the committed SQ counters of this kernel) x 4.2; what
 # the measured trip has on top of it is exposed waiting (L1 window, LDS / VMEM issue stalls).
-ISSUE_MODEL = {"cycles_per_issue_slot": 4.2, "waitcnt_and_branch_slots_per_trip": 6, "chains_per_cu": 84, "cus": 256, "clock_hz": 2.4e9}
+ISSUE_MODEL = {"cycles_per_issue_slot": 4.2, "waitcnt_and_branch_slots_per_trip": 5, "chains_per_cu": 84, "cus": 256, "clock_hz": 2.4e9}
 PROFILE_ROUNDS = ("r03", "r02")          # newest committed summary first
 
 
@@ -108,7 +108,9 @@ def issue_model():
     try:
         d = q["derived_per_wave_trip"]
         slots = d["valu"] + d["salu"] + d["lds"] + d["vmem"] + ISSUE_MODEL["waitcnt_and_branch_slots_per_trip"]
-        return {"issue_slots_per_trip": slots, "measured_cycles_per_trip": d["cycles"], "source": f"{src} @ {q.get('collected_at_commit', '?')}"}
+        return {"issue_slots_per_trip": slots, "measured_cycles_per_trip": d["cycles"],
+                "probes_per_chain_trip": d.get("probes_per_chain_trip", 1.0),       # two lanes per chain: role 1's probe counts in ~2 trips of 3
+                "source": f"{src} @ {q.get('collected_at_commit', '?')}"}
     except (TypeError, KeyError):
         return None
 
@@ -589,12 +591,13 @@ def main():
         if im:
             mdl = ISSUE_MODEL
             floor = im["issue_slots_per_trip"] * mdl["cycles_per_issue_slot"]
-            peak = mdl["cus"] * mdl["chains_per_cu"] * mdl["clock_hz"] / floor
+            peak = mdl["cus"] * mdl["chains_per_cu"] * mdl["clock_hz"] / floor * im["probes_per_chain_trip"]
             ach = R * N * probes_per_pair / (kern_ms_avg * 1e-3)
             issue_bound = {"bound": "instruction issue of one wave per SIMD x chains resident in LDS (the limiter; HBM is idle)",
                            "achieved": ach, "peak": peak, "unit": "probes/s per GPU", "frac": ach / peak,
                            "probes_per_pair": probes_per_pair,
                            "model": dict(mdl, issue_slots_per_trip=im["issue_slots_per_trip"], issue_floor_cycles_per_trip=floor,
+                                         probes_per_chain_trip=im["probes_per_chain_trip"],
                                          measured_cycles_per_trip=im["measured_cycles_per_trip"],
                                          exposed_wait_cycles_per_trip=im["measured_cycles_per_trip"] - floor, source=im["source"])}
         par = f"row-shard x{world}"

@@ -1520,6 +1520,22 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         const uint32_t cp = nn & 0x3FFFFFFFu;                     // the chain's next cursor
         const bool mp = (nn & 0x40000000u) != 0u;                 // ... after a match (put(cur-2) owed)
 
+#ifdef SNK_STATS
+        {   // wave trips, why chains ask for service (as the one-lane loop counts them), and how often the second lane counts
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) SNK_COUNT(15);
+            if (!R1) SNK_COUNT(56);
+            if (!R1 && com) SNK_COUNT(57);
+            if (!R1 && svc) {
+                if ((int32_t)lit >= 15) SNK_COUNT(16);
+                if (b >= 4u) SNK_COUNT(17);
+                if ((int32_t)op - olimZ + 14 + 3 >= 15) SNK_COUNT(18);
+                if (r == 0xFFFFFFFFu && valid) SNK_COUNT(19);
+                else if (ncur >= limc) { if (vb + ncur >= mfl1) SNK_COUNT(20); else SNK_COUNT(21); }
+                if (straddle) SNK_COUNT(22);
+            }
+        }
+#endif
         // one wave-uniform exit, decided by the chains (role 0)
         if (__builtin_amdgcn_ballot_w64(svc & !R1) != 0ull) break;
 

@@ -37,6 +37,8 @@ trips, entries = c[15], a[14]
 out = {"genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
        "wave_trips": trips, "loop_entries": entries, "trips_per_entry": trips / entries,
        "cycles_per_trip_in_loop": a[13] / trips,
+       # two lanes per chain (the default): a chain-trip is role 0's probe plus role 1's when it counted
+       "chain_trips": c[56], "second_lane_probes_counted": c[57], "probes_per_chain_trip": (c[56] + c[57]) / c[56] if c[56] else 1.0,
        "cycles_per_exit_outside_loop": (a[7] - a[13]) / entries,
        "share_outside_loop": (a[7] - a[13]) / a[7],
        "per_exit": {"finish": a[24] / entries, "general_rounds_and_reseat": a[25] / entries, "rounds": a[26] / entries, "prologue": a[27] / entries},

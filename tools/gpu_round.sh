@@ -7,11 +7,11 @@
 OUT=${1:?usage: gpu_round.sh OUT COMMIT}; COMMIT=${2:?COMMIT required}
 mkdir -p "$OUT"; export TMPDIR=/tmp
 bash tools/gpu_profiles.sh "$OUT" "$COMMIT" lz4 || exit 1
-bash tools/gpu_pmc.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1; echo "pmc groups: $(ls $OUT/pmc/pmc_*.json | wc -l)"
-python3 tools/pmc_sq_summary.py "$OUT/pmc" "$COMMIT" "$OUT/bench.json" "$OUT/pmc_sq.json" || exit 1
 if [ -f snacc_amd/libsnacc_hip_stats.so ]; then
   SNACC_HIP_LIB=$PWD/snacc_amd/libsnacc_hip_stats.so python3 tools/gpu_account.py 256 1000000 "$COMMIT" > "$OUT/cycle_account.json" 2> "$OUT/cycle_account.err"; echo "account done"
 fi
+bash tools/gpu_pmc.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1; echo "pmc groups: $(ls $OUT/pmc/pmc_*.json | wc -l)"
+python3 tools/pmc_sq_summary.py "$OUT/pmc" "$COMMIT" "$OUT/bench.json" "$OUT/pmc_sq.json" "$OUT/cycle_account.json" || exit 1
 for d in related markov; do
   python3 bench.py --data $d --cpu-seconds 5 > "$OUT/bench_$d.json" 2> "$OUT/bench_$d.err" || exit 1
   echo "bench $d: $(cut -c1-160 $OUT/bench_$d.json)"
