@@ -254,11 +254,12 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
-        const bool spec = c->fast_spec && !exc && !singles && far_waves == 0u && lanes <= 32u;
-        const void *fk = spec ? (c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_spec_cxx_kernel) : exc ? (singles ? (const void *)snk_fastx_singles_kernel
-                                        : c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_cxx_kernel)
-                             : (singles ? (const void *)snk_fast_singles_kernel
-                                        : c->fast_asm ? (const void *)snk_fast_one_kernel : (const void *)snk_fast_cxx_kernel);
+        const bool spec = c->fast_spec && !singles && far_waves == 0u && lanes <= 32u;       // two lanes per chain
+        const void *fk = singles ? (exc ? (const void *)snk_fastx_singles_kernel : (const void *)snk_fast_singles_kernel)
+                       : exc ? (spec ? (c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_spec_cxx_kernel)
+                                     : (c->fast_asm ? (const void *)snk_fastx_one_kernel : (const void *)snk_fastx_cxx_kernel))
+                             : (spec ? (c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_spec_cxx_kernel)
+                                     : (c->fast_asm ? (const void *)snk_fast_one_kernel : (const void *)snk_fast_cxx_kernel));
         HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {   // the kernel addresses its slot LUT at LDS offset 0: that holds only without static LDS
             hipFuncAttributes fa;
@@ -304,22 +305,10 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         }
         // (launches with exceptions share the context's overflow tables: one at a time, whatever their streams)
         if (exc && c->ovf_in_flight) HIPCHK(c, hipStreamWaitEvent(st, c->ovf_busy, 0));
-        if (exc && singles)
-            hipLaunchKernelGGL(snk_fastx_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (exc && c->fast_asm)
-            hipLaunchKernelGGL(snk_fastx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (exc)
-            hipLaunchKernelGGL(snk_fastx_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (singles)
-            hipLaunchKernelGGL(snk_fast_singles_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (spec && c->fast_asm)
-            hipLaunchKernelGGL(snk_fast_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (spec)
-            hipLaunchKernelGGL(snk_fast_spec_cxx_kernel, dim3(grid), dim3(64 * waves), lds, st, T, G, lanes, d_out, c->d_status);
-        else if (c->fast_asm)
-            hipLaunchKernelGGL(snk_fast_one_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
-        else
-            hipLaunchKernelGGL(snk_fast_cxx_kernel, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
+        {
+            typedef void (*SnkFastKernel)(SnkTables, SnkFastGrid, uint32_t, uint32_t *, uint32_t *);
+            hipLaunchKernelGGL((SnkFastKernel)fk, dim3(grid), dim3(64 * (waves + far_waves)), lds, st, T, G, lanes, d_out, c->d_status);
+        }
         HIPCHK(c, hipGetLastError());
         if (far_waves) { HIPCHK(c, hipEventRecord(c->far_busy, st)); c->far_in_flight = true; }
         if (exc) { HIPCHK(c, hipEventRecord(c->ovf_busy, st)); c->ovf_in_flight = true; }

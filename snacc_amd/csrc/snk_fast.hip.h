@@ -642,6 +642,40 @@ __device__ __forceinline__ bool snk_fast_iter(SnkFastLane &L, const SnkTables &T
 // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0.
 __device__ __forceinline__ uint32_t snk_ffbl(uint32_t v) { return v ? (uint32_t)__builtin_ctz(v) : 0xFFFFFFFFu; }
 
+// (sequences with exceptions) the probe at cur -- table operations done, match not evaluated -- after the steady loop
+__device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint32_t cur, uint32_t cand, const bool valid)
+{
+    if (valid && !snk_exc_clean(L, cand)) {                   // an exception near the candidate: the real bytes decide
+        SNK_COUNT_HEAVY(2);
+        snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
+    } else {
+        // Cursor and candidate windows are clean here, so the 2-bit windows -- hot in the L1 -- decide the
+        // ordinary cases exactly as the loop would; a match that may run on beyond them (back-extension 4,
+        // 12 bases forward, budget, block end) is counted on the real bytes, which may hold an exception a
+        // little further on.
+        const uint32_t wc2 = snk_fetch32(L.s, cur);
+        const uint32_t wd2 = snk_fetch32(L.s, valid ? cand : cur);
+        const uint32_t x2 = wc2 ^ wd2;
+        const uint32_t f = (uint32_t)__builtin_ctz((x2 >> 8) | (1u << 24)) >> 1;
+        if (!(valid & (f >= 4u))) {
+            const uint32_t s3 = L.nb >> 6;
+            L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
+        } else {
+            const uint32_t eq = (uint32_t)__builtin_clz(((x2 & 0xFFu) << 24) | 0x00800000u) >> 1;
+            uint32_t lit = cur - L.anchor;
+            uint32_t b = eq < lit ? eq : lit;
+            b = b < cand ? b : cand;
+            lit -= b;
+            const uint32_t e2 = cur + f, opn = L.op + lit + 3u;
+            if ((f < 12u) & (b < 4u) & (lit < 15u) & (opn + 6u <= L.olimit) & (e2 < L.mfl1)) {
+                L.op = opn; L.anchor = e2; L.cur = e2; L.step = 1u; L.nb = 63u; L.pending = true;
+            } else {
+                snk_exc_match(L, cur, cand);
+            }
+        }
+    }
+}
+
 // ---- the steady loop as gfx950 code (used by snk_fast_steady<true>) -----------------------------
 // Temporaries live in v90..v126 (clobbered).  A lone wave issues one instruction every ~4.3 cycles,
 // so a trip costs (instructions on the dependent chain) x 4.3 + the three latencies (table read,
@@ -1160,37 +1194,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         if (!snk_exc_finish_win(L, cur, cand, valid, snk_fetch32(L.s, cur), snk_fetch32m(L.s, cur)))
             snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
     } else if (EXC) {
-        const uint32_t cur = vb + c;
-        uint32_t cand = (uint32_t)(T0 + (int32_t)t);
-        if (valid && !snk_exc_clean(L, cand)) {                   // an exception near the candidate: the real bytes decide
-            SNK_COUNT_HEAVY(2);
-            snk_exc_finish(L, cur, cand, valid, snk_ld8(L.g, cur));
-        } else {
-            // Cursor and candidate windows are clean here, so the 2-bit windows -- hot in the L1 -- decide the
-            // ordinary cases exactly as the loop would; a match that may run on beyond them (back-extension 4,
-            // 12 bases forward, budget, block end) is counted on the real bytes, which may hold an exception a
-            // little further on.
-            const uint32_t wc2 = snk_fetch32(L.s, cur);
-            const uint32_t wd2 = snk_fetch32(L.s, valid ? cand : cur);
-            const uint32_t x2 = wc2 ^ wd2;
-            const uint32_t f = (uint32_t)__builtin_ctz((x2 >> 8) | (1u << 24)) >> 1;
-            if (!(valid & (f >= 4u))) {
-                const uint32_t s3 = L.nb >> 6;
-                L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
-            } else {
-                const uint32_t eq = (uint32_t)__builtin_clz(((x2 & 0xFFu) << 24) | 0x00800000u) >> 1;
-                uint32_t lit = cur - L.anchor;
-                uint32_t b = eq < lit ? eq : lit;
-                b = b < cand ? b : cand;
-                lit -= b;
-                const uint32_t e2 = cur + f, opn = L.op + lit + 3u;
-                if ((f < 12u) & (b < 4u) & (lit < 15u) & (opn + 6u <= L.olimit) & (e2 < L.mfl1)) {
-                    L.op = opn; L.anchor = e2; L.cur = e2; L.step = 1u; L.nb = 63u; L.pending = true;
-                } else {
-                    snk_exc_match(L, cur, cand);
-                }
-            }
-        }
+        snk_fast_exc_handover(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     } else {
         snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     }
@@ -1258,8 +1262,15 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cndmask_b32_e64 %[t], %[t], v103, %[ss]\n\t" \
     "v_cndmask_b32_e64 %[t], %[t], v102, %[st]\n\t" \
     "v_cndmask_b32_e32 %[t], %[t], v127, vcc\n\t" SNK_PADB
-#define SNK_SPEC_SHADOW(PH) \
-    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" \
+// (sets with exceptions, when a lane of the run may read an entry whose window holds one: the candidate's class window,
+// same offset in the class arena, ORed into the difference -- as in the one-lane loop)
+#define SNK_SPEC_MASKLOAD "global_load_dwordx2 v[88:89], v104, %[marena]\n\t"
+#define SNK_SPEC_MASKOR \
+    "v_alignbit_b32 v89, v89, v88, v109\n\t" \
+    "v_or_b32_e32 v113, v113, v89\n\t"
+#define SNK_SPEC_SHADOW(PH) SNK_SPEC_SHADOW_X(PH, "")
+#define SNK_SPEC_SHADOW_X(PH, LOAD2) \
+    "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" LOAD2 \
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
     "global_load_dword v108, %[nxoff], %[arena]\n\t" SNK_PADC \
@@ -1299,10 +1310,11 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_sub_u32_e32 v127, v112, %[five]\n\t"             /* role 0's cursor + 1 */ \
     SNK_SPEC_CUR \
     STRAD_OR
-#define SNK_SPEC_REST(LIM) \
-    "s_waitcnt vmcnt(1)\n\t" SNK_PADD \
+#define SNK_SPEC_REST(LIM) SNK_SPEC_REST_X(LIM, "", "1")
+#define SNK_SPEC_REST_X(LIM, MASKOR, W1) \
+    "s_waitcnt vmcnt(" W1 ")\n\t" SNK_PADD \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
-    "v_xor_b32_e32 v113, v113, %[wc]\n\t" \
+    "v_xor_b32_e32 v113, v113, %[wc]\n\t" MASKOR \
     "v_lshrrev_b32_e32 v114, 8, v113\n\t" \
     "v_cmp_eq_u32_sdwa vcc, v113, %[vz] src0_sel:BYTE_0 src1_sel:DWORD\n\t"   /* the 4 bases before cur are equal too */ \
     "v_ffbl_b32_e32 v114, v114\n\t" \
@@ -1367,8 +1379,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
       [sb] "=&s"(sb), [sc] "=&s"(sc) \
     : [lb] "v"(lds_off), [dma] "v"(dma), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
       [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(DUMMY), \
-      [k8] "s"(0x00800000u), [arena] "s"(arena), [r1m] "s"(r1m), [vz] "v"(0u) \
-    : "memory", "vcc", "scc", \
+      [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "v"(0u) \
+    : "memory", "vcc", "scc", "v88", "v89", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
       "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
@@ -1390,18 +1402,28 @@ __device__ __forceinline__ uint32_t snk_pair_swap(uint32_t v)          // the pa
 }
 #define SNK_PAIR_TAKE(v) do { const uint32_t sw_ = snk_pair_swap((uint32_t)(v)); if (R1) (v) = sw_; } while (0)
 
-template <bool ASM>
-__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, uint16_t *tbl, uint32_t *bm,
-                                                     uint32_t lds_off SNK_PROF_ARG)
+template <bool ASM, bool EXC>
+__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, snk_g8 *const marena,
+                                                     uint16_t *tbl, uint32_t *bm, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
 {
 #ifdef SNK_STATS
     const unsigned long long stat_te = clock64();
 #endif
     const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
     // role 1 takes the chain's state at the loop entry from role 0
-    uint32_t vb = L.base, lx = L.s.lx, xoff = L.s.xoff, yoff = L.s.yoff, mfl1 = L.mfl1, wlim = L.w.lim, olimit = L.olimit;
+    uint32_t vb = L.base, lx = L.s.lx, xoff = L.s.xoff, yoff = L.s.yoff, mfl1 = L.mfl1, olimit = L.olimit;
     uint32_t cur0 = L.cur, anchor0 = L.anchor, op = L.op, pend0 = L.pending ? 1u : 0u, wrb = L.w.rb, wsoff = L.w.soff, worg = L.w.org;
-    SNK_PAIR_TAKE(vb); SNK_PAIR_TAKE(lx); SNK_PAIR_TAKE(xoff); SNK_PAIR_TAKE(yoff); SNK_PAIR_TAKE(mfl1); SNK_PAIR_TAKE(wlim);
+    // the chain's limit, as in the one-lane loop: block end, the reservoir's source, (EXC) the next exception site, a short round
+    uint32_t lim_abs;
+    {
+        const uint32_t wlim = L.w.lim, limw = wlim == 0xFFFFFFFFu ? wlim : wlim + 1u;
+        lim_abs = L.mfl1 < limw ? L.mfl1 : limw;
+        if (EXC) lim_abs = lim_abs < L.xlim ? lim_abs : L.xlim;
+        if (EXC && round_bases != 0xFFFFFFFFu && lim_abs - L.cur > round_bases) lim_abs = L.cur + round_bases;
+    }
+    // (EXC, wave-uniform) can a chain of this run read an entry whose window holds an exception?  Only then the class window is loaded.
+    const bool need_mask = EXC && __any(!R1 && L.cur < L.mask_until);
+    SNK_PAIR_TAKE(vb); SNK_PAIR_TAKE(lx); SNK_PAIR_TAKE(xoff); SNK_PAIR_TAKE(yoff); SNK_PAIR_TAKE(mfl1); SNK_PAIR_TAKE(lim_abs);
     SNK_PAIR_TAKE(olimit); SNK_PAIR_TAKE(cur0); SNK_PAIR_TAKE(anchor0); SNK_PAIR_TAKE(op); SNK_PAIR_TAKE(pend0);
     SNK_PAIR_TAKE(wrb); SNK_PAIR_TAKE(wsoff); SNK_PAIR_TAKE(worg);
 
@@ -1410,8 +1432,6 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     const uint32_t kx = (uint32_t)X0 & 3u;
     const uint32_t xoffB = xoff + (uint32_t)(X0 >> 2), yoffB = yoff + (uint32_t)(Y0 >> 2);
     const int32_t sx = (int32_t)lx - 11 - T0;
-    const uint32_t limw = wlim == 0xFFFFFFFFu ? wlim : wlim + 1u;
-    const uint32_t lim_abs = mfl1 < limw ? mfl1 : limw;
     const uint32_t limc = lim_abs - vb;
     const int32_t olimZ = (int32_t)olimit - (int32_t)SNK_FAST_ZONE + 10;
     const uint32_t DUMMY = SNK_FSLOTS - 1u;
@@ -1441,12 +1461,21 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         uint32_t opn = op, lit;
         if (R1) op = 0u, opn = 0u;                                              // role 1 keeps no account
         uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc;
-        if (__all(sx + 15 <= 0))
-            asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
-                         SNK_SPEC_OPERANDS);
-        else
-            asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW("v103") SNK_STEADY_STRADDLE
-                         SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST("v105") SNK_SPEC_OPERANDS);
+        if (!EXC || !need_mask) {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
+                             SNK_SPEC_OPERANDS);
+            else
+                asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW("v103") SNK_STEADY_STRADDLE
+                             SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST("v105") SNK_SPEC_OPERANDS);
+        } else {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW_X("%[t]", SNK_SPEC_MASKLOAD) SNK_SPEC_PRE("")
+                             SNK_SPEC_REST_X("%[limc]", SNK_SPEC_MASKOR, "1") SNK_SPEC_OPERANDS);
+            else
+                asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW_X("v103", SNK_SPEC_MASKLOAD) SNK_STEADY_STRADDLE
+                             SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST_X("v105", SNK_SPEC_MASKOR, "1") SNK_SPEC_OPERANDS);
+        }
 #ifdef SNK_STATS
         const unsigned long long stat_t1 = clock64();
         P.loop += stat_t1 - stat_t0; P.entries++;
@@ -1460,7 +1489,8 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         }
         L.cur = vb + ccur; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (ccur - anchor_c);
         L.w.rb = 0x80000000u;
-        snk_fast_finish(L, vb + ccur, (uint32_t)(T0 + (int32_t)t), t > ccur);
+        if (EXC) snk_fast_exc_handover(L, vb + ccur, (uint32_t)(T0 + (int32_t)t), t > ccur);
+        else     snk_fast_finish(L, vb + ccur, (uint32_t)(T0 + (int32_t)t), t > ccur);
 #ifdef SNK_STATS
         P.finish += clock64() - stat_t1;
 #endif
@@ -1493,9 +1523,14 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         const bool straddle = valid & ((uint32_t)((int32_t)t - sx) < 15u);
         const uint32_t lit = c - anchor_c;
         const uint32_t wd = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, 2u * (tt & 3u));
+        uint32_t wm = 0u;                                         // (EXC) the candidate's class window: 11 where a byte is not one of ACGT
+        if (EXC && need_mask) {
+            const uint64_t mv = snk_ld8g(marena + (size_t)((inx ? xoffB : yoffB) + (tt >> 2)));
+            wm = __builtin_amdgcn_alignbit((uint32_t)(mv >> 32), (uint32_t)mv, 2u * (tt & 3u));
+        }
 
         // ---- compare, this lane's next cursor ----
-        const uint32_t x = wc ^ wd;
+        const uint32_t x = (wc ^ wd) | wm;
         const uint32_t r = snk_ffbl(x >> 8);
         const bool m = valid & (r >= 8u);
         const uint32_t e2 = c + (r >> 1);
@@ -1559,7 +1594,8 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     // role 0: hand the chain over in the state "table operations of the probe at c done, match not evaluated"
     L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
     L.w.rb = 0x80000000u;
-    snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+    if (EXC) snk_fast_exc_handover(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+    else     snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
 }
 #endif
 
@@ -1638,7 +1674,7 @@ template <bool ASM, bool EXC, bool FAR, bool SPEC = false>       // SPEC: chain 
 __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastGrid &G,
                                               uint32_t lanes, uint32_t *out, uint32_t *status)
 {
-    static_assert(!SPEC || (!EXC && !FAR), "speculative partner lanes: pure ACGT pairs");
+    static_assert(!SPEC || !FAR, "two lanes per chain: the chains with their tables in LDS");
 #ifndef SNK_HOST_EMU
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
 #endif
@@ -1741,7 +1777,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                     ((uint32_t *)dst)[t] = v;
                 }
                 if (EXC) {
-                    uint32_t *ov = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + l) * 4096u;
+                    uint32_t *ov = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + (SPEC ? l >> 1 : l)) * 4096u;
                     const uint32_t *gsrc = T.snap_gen + (size_t)xi * 4096u;
                     for (uint32_t t = lane; t < 4096u; t += SNK_COOP(64u)) ov[t] = use ? gsrc[t] : 0u;
                 }
@@ -1756,7 +1792,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                     L.g.lx = L.s.lx;
                     L.fx = T.exc_off[job.xi] != 0xFFFFFFFFu ? T.exc_flags + T.exc_off[job.xi] : nullptr;
                     L.fy = (job.yi >= 0 && T.exc_off[job.yi] != 0xFFFFFFFFu) ? T.exc_flags + T.exc_off[job.yi] : nullptr;
-                    L.ovf = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + lane) * 4096u;
+                    L.ovf = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + cidx) * 4096u;
                     L.rx = L.fx ? T.exc_runs + 2u * T.exc_roff[job.xi] : nullptr;
                     L.ry = L.fy ? T.exc_runs + 2u * T.exc_roff[job.yi] : nullptr;
                     L.ri = 0u; L.ron_y = false;
@@ -1908,9 +1944,11 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 #endif
 #ifndef SNK_HOST_EMU
         if (SPEC) {
-            const bool go = have && !parked;
+            const bool go = have && !parked && waiting == 0u && round != 0u;
             const bool pgo = snk_pair_swap(go ? 1u : 0u) != 0u;                 // (every lane of the wave is active here)
-            if (go || ((lane & 1u) && pgo)) snk_fast_steady_spec<ASM>(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, tbl, bm, mine_off SNK_PROF_PASS);
+            if (go || ((lane & 1u) && pgo))
+                snk_fast_steady_spec<ASM, EXC>(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena),
+                                               tbl, bm, mine_off, round SNK_PROF_PASS);
         } else
 #endif
         if (have && !parked && waiting == 0u && round != 0u)
@@ -1975,8 +2013,26 @@ __global__ void __launch_bounds__(512) snk_fast_singles_kernel(SnkTables T, SnkF
     snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
 }
 
-// the three again for resident sets in which some 2-bit sequence has exceptions (N runs, IUPAC codes)
+// the same again for resident sets in which some 2-bit sequence has exceptions (N runs, IUPAC codes): two lanes per chain
+// (hand-scheduled / C++ statement), one lane per chain (fast_spec = 0), singles
+template <bool ASM>
+__device__ __forceinline__ void snk_fastx_spec_body(const SnkTables &T, const SnkFastGrid &G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    snk_fast_wave<ASM, true, false, true>(T, G, lanes, out, status);
+}
 __global__ void __launch_bounds__(512) snk_fastx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fastx_spec_body<true>(T, G, lanes, out, status);
+}
+__global__ void __launch_bounds__(512) snk_fastx_spec_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fastx_spec_body<false>(T, G, lanes, out, status);
+}
+__global__ void __launch_bounds__(512) snk_fastx_one_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, true>(T, G, lanes, out, status);
 }

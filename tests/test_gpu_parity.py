@@ -314,13 +314,13 @@ def test_sequences_with_a_few_exceptions_stay_on_the_2bit_kernel(hip, oracle_mod
         ss = seqs + extra
         exp_s = np.array([o.lz4f_size(x) for x in ss], dtype=np.uint32)
         exp_p = np.array([[o.lz4f_size_pair(a, b) for b in ss] for a in ss], dtype=np.uint32)
-        for asm in (1, 0):
-            with hip.HipContext(0, fast_asm=asm, exc_limit=8192, fast_lanes=5, fast_waves=2) as ctx:
+        for asm, spec in ((1, 1), (0, 1), (1, 0), (0, 0)):           # hand-scheduled / C++ statement; two lanes per chain / one
+            with hip.HipContext(0, fast_asm=asm, fast_spec=spec, exc_limit=8192, fast_lanes=5, fast_waves=2) as ctx:
                 ctx.upload(ss)
                 assert ctx.num_packed == packed
                 s, p = ctx.singles(), ctx.pairs()
-            assert np.array_equal(s, exp_s), (asm, np.flatnonzero(s != exp_s))
-            assert np.array_equal(p, exp_p), (asm, np.argwhere(p != exp_p)[:8].tolist())
+            assert np.array_equal(s, exp_s), (asm, spec, np.flatnonzero(s != exp_s))
+            assert np.array_equal(p, exp_p), (asm, spec, np.argwhere(p != exp_p)[:8].tolist())
     with hip.HipContext(0, exc_limit=0) as ctx:          # the option off: such sequences take the byte kernel, same sizes
         ctx.upload(seqs)
         assert ctx.num_packed == 1
