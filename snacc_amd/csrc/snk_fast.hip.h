@@ -731,12 +731,11 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
     "v_lshl_add_u32 v92, v92, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
     "ds_or_rtn_b32 v94, v92, v93 offset:1792\n\t" SNK_PADA \
-    "v_add_u32_e32 v96, -2, %[c]\n\t" \
-    "v_add_u32_e32 v99, 0xfffe, %[c]\n\t" \
+    "v_add_u32_e32 v99, 0xfffe, %[c]\n\t"               /* cur - 2 in this block: the patch below, and (low 16 bits) the data of the owed put */ \
     "s_waitcnt lgkmcnt(2)\n\t" \
     "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot */ \
     "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
-    "ds_write_b16 v95, v96\n\t" \
+    "ds_write_b16 v95, v99\n\t" \
     "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t" \
     "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
@@ -1215,23 +1214,21 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 //    itself (limit, straddling candidate, 12 equal bases) ends the loop and is handed over in role 0's place;
 //  * the chain's accounting is committed one trip late, in the shadow of the candidate load (masks sq / scm / sc0).
 #define SNK_SPEC_DEF_X(VAL) \
-    "s_and_b64 %[ss], %[sc], %[r1m]\n\t"                /* role 1's puts, if its probe counted (else the unused slot / no bit) */ \
-    "v_cndmask_b32_e64 v100, %[dma], v95, %[ss]\n\t" \
-    "v_cndmask_b32_e64 v101, 0, v98, %[ss]\n\t" \
-    "v_cndmask_b32_e64 v102, %[dma], v90, %[ss]\n\t" \
-    "v_cndmask_b32_e64 v103, 0, v93, %[ss]\n\t" \
-    "ds_write_b16 v100, v96\n\t" \
-    "ds_or_b32 v97, v101 offset:1792\n\t" \
-    "ds_write_b16 v102, " VAL "\n\t" \
-    "ds_or_b32 v92, v103 offset:1792\n\t"
+    "s_and_b64 exec, %[sc], %[r1m]\n\t"                 /* role 1's puts, if its probe counted: the other lanes sit the four operations out */ \
+    "ds_write_b16 v95, v127\n\t"                        /* (issued and counted all the same: the waits at the top see four operations every trip) */ \
+    "ds_or_b32 v97, v98 offset:1792\n\t" \
+    "ds_write_b16 v90, " VAL "\n\t" \
+    "ds_or_b32 v92, v93 offset:1792\n\t" \
+    "s_mov_b64 exec, %[ex]\n\t"
 // (measured the same within the noise between boxes, ~0.5 %: these puts before the cursor update instead -- one instruction
 // fewer -- and one or two waits for the two slots at the top)
 #define SNK_SPEC_DEF_A
 #define SNK_SPEC_DEF_B SNK_SPEC_DEF_X("v104")
 #define SNK_SPEC_W0 "4"
 #define SNK_SPEC_W1
-#define SNK_SPEC_CUR "v_add_u32_e32 v104, 2, v96\n\t"
+#define SNK_SPEC_CUR "v_add_u32_e32 v104, 2, v127\n\t"      /* this trip's cursor (+ 65536: 16-bit data of role 1's put) */
 #define SNK_SPEC_TABLE \
+    "s_mov_b64 %[ex], exec\n\t"                         /* the lanes of the loop */ \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(" SNK_SPEC_W0 ")\n\t"            /* the slots of cur and cur-2 (behind them: role 1's four put operations) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
@@ -1247,8 +1244,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_add_u32_e32 v102, 0xfffb, %[c]\n\t"              /* role 1: the partner's put(cur) = this cursor - 5 */ \
     "v_add_u32_e32 v103, 0xfff9, %[c]\n\t"              /* ... its put(cur-2) */ \
     "v_lshl_or_b32 v100, %[s2], 16, %[s1]\n\t"          /* both slots, for the partner */ \
-    "v_add_u32_e32 v127, 0xfffe, %[c]\n\t" \
-    "v_add_u32_e32 v96, -2, %[c]\n\t" \
+    "v_add_u32_e32 v127, 0xfffe, %[c]\n\t"              /* cur - 2 in this block: role 1's patch, and (low 16 bits) the data of put(cur-2) */ \
     "v_mov_b32_dpp v101, v100 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
     "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
     "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
@@ -1278,7 +1274,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
     "s_andn2_b64 exec, exec, %[r1m]\n\t" \
-    "ds_write_b16 v95, v96\n\t" \
+    "ds_write_b16 v95, v127\n\t" \
     "ds_or_b32 v97, v98 offset:1792\n\t" \
     "ds_write_b16 v90, %[c]\n\t" \
     "s_or_b64 exec, exec, %[r1m]\n\t" \
@@ -1307,7 +1303,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cmp_lt_i32_e64 %[sp], 14, v122\n\t" \
     "v_cmp_lt_u32_e64 %[sb], 3, %[lit]\n\t" \
     "v_cndmask_b32_e64 v119, v119, -2, %[st]\n\t" \
-    "v_sub_u32_e32 v127, v112, %[five]\n\t"             /* role 0's cursor + 1 */ \
+    "v_sub_u32_e32 v96, v112, %[five]\n\t"              /* role 0's cursor + 1 */ \
     SNK_SPEC_CUR \
     STRAD_OR
 #define SNK_SPEC_REST(LIM) SNK_SPEC_REST_X(LIM, "", "1")
@@ -1329,19 +1325,18 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_cndmask_b32_e64 v117, v115, -1, %[sp]\n\t" \
     "v_lshl_or_b32 v120, v113, 24, %[k8]\n\t" \
     "v_ffbh_u32_e32 v120, v120\n\t" \
-    "v_mov_b32_dpp v121, v117 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_cndmask_b32_e64 v122, v117, v121, %[r1m]\n\t"    /* role 0's next cursor, in both lanes */ \
-    "v_cndmask_b32_e64 v123, v121, v117, %[r1m]\n\t"    /* role 1's */ \
+    "v_mov_b32_dpp v122, v117 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   /* role 0's next cursor, in both lanes */ \
+    "v_mov_b32_dpp v123, v117 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   /* role 1's */ \
     "v_cmp_eq_u32_e64 %[sc], v122, v119\n\t"            /* role 0's match ends where role 1 probed: both count */ \
     "v_lshrrev_b32_e32 v120, 1, v120\n\t" \
-    "v_add_u32_e32 v118, 5, v127\n\t"                   /* role 1's cursor + 1 */ \
+    "v_add_u32_e32 v118, 5, v96\n\t"                    /* role 1's cursor + 1 */ \
     SNK_SPEC_DEF_A \
     "v_cndmask_b32_e64 v122, v122, v123, %[sc]\n\t"     /* the chain's next cursor */ \
     "v_add_u32_e32 %[c], v122, %[five]\n\t"             /* this lane's */ \
     "v_sub_u32_e32 v116, %[c], %[rbc]\n\t" \
     "v_cmp_lt_u32_e64 %[sl], 15, v116\n\t" \
     "v_lshlrev_b32_e32 v116, 1, v116\n\t" \
-    "v_cndmask_b32_e64 v118, v127, v118, %[sc]\n\t"     /* cursor + 1 of the last probe that counted */ \
+    "v_cndmask_b32_e64 v118, v96, v118, %[sc]\n\t"      /* cursor + 1 of the last probe that counted */ \
     "s_waitcnt vmcnt(0)\n\t" \
     "v_cndmask_b32_e64 %[r0], %[r0], %[r1], %[sl]\n\t" \
     "v_cndmask_b32_e64 %[r1], %[r1], v108, %[sl]\n\t" \
@@ -1376,8 +1371,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
       [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
       [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), \
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sq] "=&s"(sq), [sp] "=&s"(sp), \
-      [sb] "=&s"(sb), [sc] "=&s"(sc) \
-    : [lb] "v"(lds_off), [dma] "v"(dma), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
+      [sb] "=&s"(sb), [sc] "=&s"(sc), [ex] "=&s"(ex) \
+    : [lb] "v"(lds_off), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
       [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(DUMMY), \
       [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "v"(0u) \
     : "memory", "vcc", "scc", "v88", "v89", \
@@ -1455,12 +1450,12 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
 #endif
     if (ASM) {
         const uint64_t r1m = __builtin_amdgcn_ballot_w64(R1);                   // role 1 among the lanes in the loop
-        const uint32_t five = R1 ? 5u : 0u, dma = lds_off + 2u * DUMMY;
+        const uint32_t five = R1 ? 5u : 0u;
         const uint32_t oz = (uint32_t)(olimZ - 14 - 3);
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         uint32_t opn = op, lit;
         if (R1) op = 0u, opn = 0u;                                              // role 1 keeps no account
-        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc;
+        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc, ex;
         if (!EXC || !need_mask) {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
