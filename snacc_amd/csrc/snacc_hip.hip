@@ -38,6 +38,7 @@ struct snk_ctx_impl {
     hipEvent_t far_busy = nullptr; bool far_in_flight = false;   // ... in use until the launch that got them ends
     uint32_t *d_bgt = nullptr; size_t bgt_bytes = 0;     // global-memory tables of the byte kernels ("bytes_gt"), same rules
     hipEvent_t bgt_busy = nullptr; bool bgt_in_flight = false;
+    int bytes_spec = 0;                                  // LDS byte kernels on the slot stream: two lanes per chain (snk_bytes_loop2_spec)
     int bytes_gt = -1, bytes_gt_wgs = 1;                 // waves per workgroup (0 = tables in LDS, -1 = choose), workgroups per CU and launch
     int far_lanes = 0, far_waves = 4; // far_lanes 0 = no far chains
     int far_min = 4;                 // far chains only in launches of at least far_min jobs per LDS chain of the card (0: always; tests)
@@ -358,7 +359,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const uint32_t chains = lanes * waves;
         const size_t chain_b = big ? SnkBT<2048, false>::CHAIN_B : SnkBT<1024, false>::CHAIN_B;
         const size_t lds = (size_t)SnkBT<1024, false>::LUT_B + (size_t)chains * chain_b;
-        const void *kern = big ? (const void *)snk_bytes_compact2k_kernel : (const void *)snk_bytes_compact_kernel;
+        const bool spec = c->bytes_spec && c->d_slots && lanes <= 32u;       // two lanes per chain
+        const void *kern = spec ? (big ? (const void *)snk_bytes_compact2k_spec_kernel : (const void *)snk_bytes_compact_spec_kernel)
+                                : (big ? (const void *)snk_bytes_compact2k_kernel : (const void *)snk_bytes_compact_kernel);
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "%u compact byte chains exceed the 160 KiB LDS (max %d)", chains, big ? 35 : 70);
         HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -369,12 +372,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                 return fail(c, SNK_E_STATE, "compact byte kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
         }
         const uint32_t grid = (uint32_t)((n_bytes + chains - 1) / chains);
-        if (big)
-            hipLaunchKernelGGL(snk_bytes_compact2k_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                               T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
-        else
-            hipLaunchKernelGGL(snk_bytes_compact_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                               T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        {
+            typedef void (*SnkBytesKernel)(SnkTables, const SnkJob *, uint32_t, uint32_t, uint32_t *, uint32_t *);
+            hipLaunchKernelGGL((SnkBytesKernel)kern, dim3(grid), dim3(64 * waves), lds, st,
+                               T, (const SnkJob *)(d_jobs + n_fast), (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        }
         HIPCHK(c, hipGetLastError());
     } else if (n_bytes) {
         const uint32_t lanes = (uint32_t)c->bytes_lanes, waves = (uint32_t)c->bytes_waves;
@@ -382,11 +384,15 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const size_t lds = (size_t)chains * SnkBT<0, false>::CHAIN_B;
         if (lds > 160 * 1024)
             return fail(c, SNK_E_ARG, "bytes_lanes*bytes_waves = %u chains exceed the 160 KiB LDS (max 18)", chains);
-        HIPCHK(c, hipFuncSetAttribute((const void *)snk_bytes_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const bool spec = c->bytes_spec && c->d_slots && lanes <= 32u;
+        const void *kern = spec ? (const void *)snk_bytes_spec_kernel : (const void *)snk_bytes_kernel;
+        HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t grid = (uint32_t)((n_bytes + chains - 1) / chains);
-        hipLaunchKernelGGL(snk_bytes_kernel, dim3(grid), dim3(64 * waves), lds, st,
-                           T, d_jobs + n_fast, (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        {
+            typedef void (*SnkBytesKernel)(SnkTables, const SnkJob *, uint32_t, uint32_t, uint32_t *, uint32_t *);
+            hipLaunchKernelGGL((SnkBytesKernel)kern, dim3(grid), dim3(64 * waves), lds, st,
+                               T, (const SnkJob *)(d_jobs + n_fast), (uint32_t)n_bytes, lanes, d_out, c->d_status);
+        }
         HIPCHK(c, hipGetLastError());
     }
     n_bytes = n_bytes_all;
@@ -653,6 +659,9 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
     } else if (k == "gen_chains") {
         if (value < 1 || value > 9) return fail(c, SNK_E_ARG, "gen_chains must be 1..9");
         c->gen_chains = (int)value;
+    } else if (k == "bytes_spec") {
+        if (value < 0 || value > 1) return fail(c, SNK_E_ARG, "bytes_spec must be 0 or 1");
+        c->bytes_spec = (int)value;
     } else if (k == "bytes_gt") {
         if (value < -1 || value > 8) return fail(c, SNK_E_ARG, "bytes_gt must be -1..8 (waves per workgroup; 0 = tables in LDS, -1 = choose)");
         c->bytes_gt = (int)value;

@@ -512,14 +512,172 @@ __device__ __forceinline__ void snk_bytes_loop2(SnkByteLane &L, const SnkTables 
     }
 }
 
+// ---- slot-stream loop with a speculative partner lane per chain (round 3, "bytes_spec") -----------------------------
+// The LDS byte kernels wait for memory on every trip (candidate window from a 64 KiB history, then the next probe's
+// slots + window) with at most 70 chains per CU and 17 of a wave's 64 lanes in use.  As in the 2-bit kernel
+// (snk_fast_steady_spec) the idle lanes run the SAME chain ahead: every chain is a DPP pair (2i, 2i+1); lane 2i ("role 0")
+// is the chain, lane 2i+1 ("role 1") probes at cur + 5 in the same trip exactly as liblz4's immediate probe after a
+// 5-byte match would (put(cur + 3) owed, no literals, step 1).  Role 1 READS the table with everybody -- role 0's owed put
+// has been issued before the read, its put(cur) and role 1's own owed put are patched into the result by selects, in
+// liblz4's order -- and WRITES nothing until its probe is known to count: role 0's probe is an ordinary match that ends
+// exactly where role 1 probed, and role 1's own probe needs no rare path and no limit handling (else it is dropped and
+// role 0 makes that probe itself in the next trip: exactness never rests on the guess).  General probes, block steps
+// and the rare paths are role 0's alone; role 1 takes the chain's state again at every entry of the tight loop.
+__device__ __forceinline__ uint32_t snk_bpair_swap(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+template <int CAP>
+__device__ __forceinline__ void snk_bytes_loop2_spec(SnkByteLane &L, const bool R1, const SnkTables &T, uint16_t *tbl, uint32_t *bm,
+                                                     uint32_t *out, uint32_t *status)
+{
+    constexpr uint32_t DUMMY = SnkBT<CAP, false>::DUMMY;
+    snk_g8 *const arena = L.s.arena;
+    const SNK_AS1 uint16_t *const slots = (const SNK_AS1 uint16_t *)T.slots;
+    bool done = false;
+    for (;;) {
+        // ---- role 0 brings its chain to a cursor the tight loop can serve; role 1 waits ----
+        for (;;) {
+            bool pre = false;
+            if (!R1 && !done) {
+                const uint32_t cur = L.cur, next = cur + L.step;
+                pre = (next > L.mfl1) | (cur > L.w.lim) | (cur < L.w.org + 4u);
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pre) == 0ull, 1)) break;
+            if (pre && snk_bytes_iter_slow<CAP, false, false>(L, T, tbl, bm, out, status)) done = true;
+        }
+        {   // a finished chain leaves with both its lanes
+            const bool pdone = snk_bpair_swap(done ? 1u : 0u) != 0u;
+            if (R1 ? pdone : done) return;
+        }
+        // ---- entry: role 1 takes the chain's state ----
+        uint32_t cur = L.cur, step = L.step, nb = L.nb, anchor = L.anchor, op = L.op, pend = L.pending ? 1u : 0u;
+        uint32_t base = L.base, mfl1 = L.mfl1, mlimit = L.mlimit, olimit = L.olimit, wsoff = L.w.soff, worg = L.w.org, wlim = L.w.lim;
+        {
+            const uint32_t a0 = snk_bpair_swap(cur), a1 = snk_bpair_swap(base), a2 = snk_bpair_swap(mfl1), a3 = snk_bpair_swap(mlimit);
+            const uint32_t a4 = snk_bpair_swap(olimit), a5 = snk_bpair_swap(wsoff), a6 = snk_bpair_swap(worg), a7 = snk_bpair_swap(wlim);
+            if (R1) { cur = a0 + 5u; base = a1; mfl1 = a2; mlimit = a3; olimit = a4; wsoff = a5; worg = a6; wlim = a7;
+                      step = 1u; nb = 63u; anchor = cur; op = 0u; pend = 1u; }
+        }
+        const uint32_t olim6 = olimit - 6u;
+        // this lane's slots (cur-2 .. cur+1) and 12-byte window; a role-1 cursor beyond the limits loads its partner's (never offered)
+        uint32_t lc = (R1 && ((cur > mfl1) | (cur > wlim))) ? cur - 5u : cur;
+        uint32_t so = wsoff + (lc - worg);
+        uint64_t sv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)so - 2u))->v;
+        SnkW12 w;
+        { const SNK_AS1 SnkU96 *wp = (const SNK_AS1 SnkU96 *)(arena + (size_t)so - 4u); w.a = wp->a; w.b = wp->b; w.c = wp->c; }
+
+        for (;;) {
+            const uint32_t s1 = (uint32_t)(sv >> 32) & 0xFFFFu;
+            const uint32_t s2 = (R1 || pend) ? ((uint32_t)sv & 0xFFFFu) : DUMMY;
+            const uint32_t c = cur - base;
+            // ---- table, liblz4's order for the chain: role 0 put(cur-2) [owed], get(cur), put(cur); role 1 only reads ----
+            const uint32_t b2 = R1 ? DUMMY : s2, b1 = R1 ? DUMMY : s1;
+            const uint32_t bit1 = 1u << (s1 & 31u);
+            tbl[b2] = (uint16_t)(c - 2u);
+            atomicOr(&bm[b2 >> 5], 1u << (b2 & 31u));
+            const uint32_t e = tbl[s1];
+            const uint32_t bw = atomicOr(&bm[s1 >> 5], R1 ? 0u : bit1);
+            tbl[b1] = (uint16_t)c;
+            const bool iscur = (bw & bit1) != 0u;
+            uint32_t cand = base + e - (iscur ? 0u : 65536u);
+            bool valid = iscur | (e > c);
+            {   // role 1: role 0's put(cur) of this trip and its own owed put have not been written
+                const uint32_t ps1 = snk_bpair_swap(s1);
+                if (R1 && ps1 == s1) { cand = cur - 5u; valid = true; }
+                if (R1 && s2 == s1)  { cand = cur - 2u; valid = true; }
+            }
+            cand = valid ? cand : cur;
+            const SnkW12 wd = snk_bfetch12(L.s, cand);
+
+            const uint32_t x0 = w.a ^ wd.a, x1 = w.b ^ wd.b, x2 = w.c ^ wd.c;
+            uint32_t fh = (uint32_t)__builtin_ctz(x2 | 0x80000000u) >> 3;
+            fh = x2 ? fh : 4u;
+            const uint32_t f = x1 ? ((uint32_t)__builtin_ctz(x1) >> 3) : 4u + fh;
+            const uint32_t eq = x0 ? ((uint32_t)__builtin_clz(x0) >> 3) : 4u;
+            const bool m = valid & (x1 == 0u);
+            uint32_t e2 = cur + f;
+            const bool clipped = e2 >= mlimit;
+            e2 = e2 < mlimit ? e2 : mlimit;
+            const uint32_t s3 = nb >> 6;
+            const uint32_t nstep = m ? 1u : (s3 ? s3 : 1u);
+            const uint32_t next = cur + step;
+            const uint32_t ncur = m ? e2 : next;
+            const uint32_t nnext = ncur + nstep;
+
+            // ---- this probe's account (role 1: no literals, nothing before the cursor to catch up) ----
+            uint32_t lit = cur - anchor;
+            uint32_t b = eq < lit ? eq : lit;
+            b = b < cand ? b : cand;
+            lit -= b;
+            const uint32_t opn = op + lit + 3u;
+            const bool rare = m & ((b == 4u) | (f == 8u) | (lit >= 15u) | (opn > olim6));
+            const bool pre = (nnext > mfl1) | (ncur > wlim);
+
+            // ---- the pair decides ----
+            // role 0 offers "an ordinary match that ends where role 1 probed, with room for role 1's sequence";
+            // role 1 offers "a probe the tight loop may make, that needs neither a rare path nor limit handling"
+            const bool offer = R1 ? ((next <= mfl1) & (cur <= wlim) & !rare & !pre)
+                                  : (m & (f == 5u) & !clipped & !rare & !pre & (opn + 3u <= olim6));
+            const uint32_t pk = (ncur & 0x3FFFFFFFu) | (m ? 0x40000000u : 0u) | (offer ? 0x80000000u : 0u);
+            const uint32_t qk = snk_bpair_swap(pk);
+            const bool com = offer & ((int32_t)qk < 0);                 // role 1's probe counts (the same value in both lanes)
+            if (R1 && com) {                                            // ... its two puts, after role 0's (liblz4's order)
+                tbl[s2] = (uint16_t)(c - 2u);
+                atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
+                tbl[s1] = (uint16_t)c;
+                atomicOr(&bm[s1 >> 5], bit1);
+            }
+            const uint32_t n1 = R1 ? pk : qk;                           // (next cursor, matched) of role 1's probe
+            const bool m1 = (n1 & 0x40000000u) != 0u;
+            const uint32_t cp = com ? (n1 & 0x3FFFFFFFu) : (R1 ? (qk & 0x3FFFFFFFu) : ncur);   // the chain's next cursor
+
+            // ---- commit (role 0 keeps the chain's account) ----
+            const uint32_t anchor0 = anchor, op0 = op;
+            if (!R1) {
+                op = m ? opn : op0;
+                anchor = m ? e2 : anchor0;
+                step = nstep;
+                nb = m ? 63u : nb + 1u;
+                pend = m ? 1u : 0u;
+                if (com) {                                              // role 1's probe: token + offset when it matched
+                    op += m1 ? 3u : 0u;
+                    anchor = m1 ? cp : anchor;
+                    step = 1u;
+                    nb = m1 ? 63u : 64u;
+                    pend = m1 ? 1u : 0u;
+                }
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!R1 & (rare | pre)) != 0ull, 0)) {
+                if (!R1) {
+                    L.op = op; L.anchor = anchor; L.step = step; L.nb = nb; L.cur = cp; L.pending = pend != 0u;
+                    if (rare) snk_bytes_match_slow(L, cur, cand, anchor0, op0);
+                }
+                break;
+            }
+            // ---- the next probe's data ----
+            const uint32_t ncl = R1 ? cp + 5u : cp;
+            if (R1) anchor = ncl;
+            lc = (R1 && ((ncl > mfl1) | (ncl > wlim))) ? cp : ncl;
+            const uint32_t nso = wsoff + (lc - worg);
+            sv = ((const SNK_AS1 SnkU64p *)(slots + (size_t)nso - 2u))->v;
+            { const SNK_AS1 SnkU96 *nwp = (const SNK_AS1 SnkU96 *)(arena + (size_t)nso - 4u); w.a = nwp->a; w.b = nwp->b; w.c = nwp->c; }
+            cur = ncl; so = nso;
+        }
+    }
+}
+
 // grid: one workgroup per `lanes*waves` jobs; dynamic LDS = LUT_B + CHAIN_B per chain.
-template <int CAP, bool ONESHOT>
+// SPEC: two lanes per chain (snk_bytes_loop2_spec): chain l of a wave is the lane pair (2l, 2l+1); `lanes` stays the number
+// of chains per wave (<= 32).
+template <int CAP, bool ONESHOT, bool SPEC = false>
 __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const SnkJob *jobs, uint32_t n_jobs,
                                                       uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     typedef SnkBT<CAP, ONESHOT> G;
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = SPEC ? (tid & 63u) >> 1 : tid & 63u, wave = tid >> 6;     // lane: the chain's number in its wave
+    const bool R1 = SPEC && (tid & 1u);
     const uint32_t waves = blockDim.x >> 6;
     const uint32_t chains = lanes * waves;
     const uint32_t c = lane * waves + wave;
@@ -536,17 +694,18 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     SnkJob job; job.xi = 0; job.yi = -1; job.out_idx = 0; job.snap = 0;
     if (active) job = jobs[j];
 
+    const uint32_t ilane = tid & 63u;                              // (the table fills below are by the wave's 64 lanes)
     for (uint32_t l = 0; l < lanes; ++l) {
-        const int a   = __shfl((int)active, (int)l);
-        const int xi  = __shfl(job.xi, (int)l);
-        const int snp = __shfl(job.snap, (int)l);
+        const int a   = __shfl((int)active, (int)(SPEC ? 2u * l : l));
+        const int xi  = __shfl(job.xi, (int)(SPEC ? 2u * l : l));
+        const int snp = __shfl(job.snap, (int)(SPEC ? 2u * l : l));
         if (!a) continue;
         uint8_t *dst = snk_lds8 + G::LUT_B + (size_t)(wave * lanes + l) * G::CHAIN_B;
         const uint32_t spos = T.snap_pos[xi];
         const bool use = !ONESHOT && (snp == 0) && (spos != 0u);
         const uint32_t *src = T.snap_gen + (size_t)xi * 4096u;
         if (CAP == 0) {
-            for (uint32_t t = lane; t < G::TBL_B / 4u; t += 64u) {
+            for (uint32_t t = ilane; t < G::TBL_B / 4u; t += 64u) {
                 uint32_t v = 0u;
                 if (use && t < 2048u) {
                     const uint32_t a0 = src[2u * t], a1 = src[2u * t + 1u];
@@ -557,18 +716,18 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
                 ((uint32_t *)dst)[t] = v;
             }
         } else {
-            for (uint32_t t = lane; t < G::TBL_B / 4u; t += 64u) ((uint32_t *)dst)[t] = 0u;
+            for (uint32_t t = ilane; t < G::TBL_B / 4u; t += 64u) ((uint32_t *)dst)[t] = 0u;
             if (use) {
                 // scatter liblz4's hash-indexed snapshot into the renamed slots (LDS ops of a wave are
                 // executed in issue order, so the zero fill above lands first)
-                for (uint32_t h = lane; h < 4096u; h += 64u) {
+                for (uint32_t h = ilane; h < 4096u; h += 64u) {
                     const uint32_t id = snk_bslot<true>(h);
                     const uint32_t a0 = src[h];
                     if (id != SNK_BC_NOSLOT) ((uint16_t *)dst)[id] = (uint16_t)((a0 + 65536u >= spos) ? (a0 & 0xFFFFu) : 0u);
                 }
             }
         }
-        for (uint32_t t = lane; t < G::BMWORDS; t += 64u)
+        for (uint32_t t = ilane; t < G::BMWORDS; t += 64u)
             ((uint32_t *)(dst + G::TBL_B))[t] = use ? 0u : 0xFFFFFFFFu;
     }
     __syncthreads();
@@ -596,8 +755,9 @@ __device__ __forceinline__ void snk_bytes_kernel_body(const SnkTables &T, const 
     L.pending = false;
     L.w.soff = L.s.xoff; L.w.org = 0u; L.w.rb = 0u; L.w.lim = 0u;
     L.w.r0 = L.w.r1 = L.w.r2 = L.w.r3 = L.w.r4 = L.w.r5 = L.w.nx0 = L.w.nx1 = 0u;
-    if (!ONESHOT && T.slots) snk_bytes_loop2<CAP>(L, T, tbl, bm, out, status);
-    else                     snk_bytes_loop<CAP, ONESHOT>(L, T, tbl, bm, out, status);
+    if (SPEC)                     snk_bytes_loop2_spec<CAP>(L, R1, T, tbl, bm, out, status);     // (launched only with a slot stream)
+    else if (!ONESHOT && T.slots) snk_bytes_loop2<CAP>(L, T, tbl, bm, out, status);
+    else                          snk_bytes_loop<CAP, ONESHOT>(L, T, tbl, bm, out, status);
 }
 
 
@@ -705,6 +865,23 @@ __global__ void snk_bytes_compact2k_kernel(SnkTables T, const SnkJob *jobs, uint
                                            uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_bytes_kernel_body<2048, false>(T, jobs, n_jobs, lanes, out, status);
+}
+
+// two lanes per chain (linked mode on the slot stream; "bytes_spec")
+__global__ void snk_bytes_spec_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                      uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<0, false, true>(T, jobs, n_jobs, lanes, out, status);
+}
+__global__ void snk_bytes_compact_spec_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                              uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<1024, false, true>(T, jobs, n_jobs, lanes, out, status);
+}
+__global__ void snk_bytes_compact2k_spec_kernel(SnkTables T, const SnkJob *jobs, uint32_t n_jobs,
+                                                uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_bytes_kernel_body<2048, false, true>(T, jobs, n_jobs, lanes, out, status);
 }
 
 // one-shot mode (n <= 64 KiB): full 8192-slot table, and the compact form

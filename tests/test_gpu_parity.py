@@ -108,6 +108,38 @@ def test_byte_kernels_with_tables_in_global_memory(hip, oracle_mod):
     _check_all(hip, o, mixed, bytes_gt=8, bytes_gt_wgs=2)
 
 
+def test_byte_kernels_with_two_lanes_per_chain(hip, oracle_mod):
+    """bytes_spec: the LDS byte kernels' slot-stream loop with a speculative partner lane per chain (the second lane
+    probes 5 bytes ahead; its probe counts when the first lane's match ends there).  The same sets as the one-lane
+    forms -- ragged block edges, long matches, low complexity, seam strings outside the compact set, raw blocks,
+    soft-masked text, protein -- both settings of the option against the oracle, and against each other."""
+    o = oracle_mod
+    lens = [65537, 131072, 200001, 70000, 65535 + 65536, 65548, 196608]
+    seqs = [o.lcg_genome(11 + i, n) for i, n in enumerate(lens)]
+    rep = np.tile(o.lcg_genome(32, 5000), 40)
+    seqs += [np.tile(o.lcg_genome(31, 37), 3000), rep, o.lcg_mutant(rep, 5),
+             np.frombuffer(b"A" * 150000, dtype=np.uint8), np.frombuffer(b"AC" * 60000, dtype=np.uint8),
+             np.frombuffer(b"N" * 1000 + bytes(o.lcg_genome(77, 90000)) + b"n" * 3000, dtype=np.uint8),
+             np.frombuffer(bytes(o.lcg_genome(78, 66000)) + b"NNNN", dtype=np.uint8),
+             np.frombuffer(b"NNNN" + bytes(o.lcg_genome(79, 80000)), dtype=np.uint8)]
+    for spec in (0, 1):
+        _check_all(hip, o, seqs, force_generic=1, bytes_spec=spec)                               # compact, 1024 slots
+        _check_all(hip, o, seqs, force_generic=1, bytes_spec=spec, cbytes_lanes=3, cbytes_waves=2)   # few chains: trips in which no second lane counts
+        _check_all(hip, o, seqs[:8], force_generic=1, bytes_compact=0, bytes_gt=0, bytes_spec=spec)  # full table in LDS
+    soft = [np.frombuffer(bytes(x[:40000]) + bytes(x[40000:]).lower(), dtype=np.uint8) for x in seqs[:6]]
+    exp = np.array([[o.lz4f_size_pair(a, b) for b in soft] for a in soft], dtype=np.uint32)
+    for spec in (0, 1):
+        with hip.HipContext(0, force_generic=1, bytes_gt=0, bytes_spec=spec) as ctx:            # compact, 2048 slots (both cases)
+            ctx.upload(soft)
+            assert 1024 < ctx.num_compact_hashes <= 2048
+            assert np.array_equal(ctx.pairs(), exp)
+    rng = np.random.default_rng(7)
+    mixed = [o.lcg_genome(21, 150000), rng.integers(0, 256, 140000, dtype=np.uint8),
+             np.frombuffer(lcg_bytes(31, 90000, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8),
+             np.frombuffer(lcg_bytes(32, 70001, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8)]
+    _check_all(hip, o, mixed, bytes_gt=0, bytes_spec=1)
+
+
 def test_global_table_byte_kernel_is_the_default_for_large_full_table_launches(hip, oracle_mod):
     """Protein sequences (full table): a launch with more jobs than two rounds of the LDS kernel takes the
     global-table kernel by itself.  144 x 144 pairs at one workgroup of 64 chains per CU and launch = two

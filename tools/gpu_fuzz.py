@@ -8,6 +8,7 @@ from oracle.loader import pairs_mt
 from snacc_amd import hip_backend as hip
 
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+BSPEC_DEFAULT = 0      # the library's default of "bytes_spec" (the fuzz runs the other setting as extra configurations)
 
 
 def gen(rng, n, kind):
@@ -80,6 +81,8 @@ def one(seed):
     for opts in ({}, {"fast_asm": 0}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
                  {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2},
                  {"force_generic": 1, "bytes_gt": 2}, {"force_generic": 1, "bytes_compact": 0, "bytes_gt": 3},      # tables in global memory
+                 {"force_generic": 1, "bytes_spec": 1 - BSPEC_DEFAULT}, {"force_generic": 1, "bytes_compact": 0, "bytes_gt": 0, "bytes_spec": 1 - BSPEC_DEFAULT},   # byte kernels, the other number of lanes per chain
+                 {"force_generic": 1, "bytes_spec": 1 - BSPEC_DEFAULT, "cbytes_lanes": 3, "cbytes_waves": 2},
                  {"exc_limit": 16384}, {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0}):            # ... one lane per chain (the default has two)                                                                             # dense exceptions stay on the 2-bit kernel
         with hip.HipContext(0, **opts) as ctx:
             ctx.upload(seqs)
