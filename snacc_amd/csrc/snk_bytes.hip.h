@@ -622,6 +622,7 @@ __device__ __forceinline__ void snk_bytes_loop2_spec(SnkByteLane &L, const bool 
             const uint32_t pk = (ncur & 0x3FFFFFFFu) | (m ? 0x40000000u : 0u) | (offer ? 0x80000000u : 0u);
             const uint32_t qk = snk_bpair_swap(pk);
             const bool com = offer & ((int32_t)qk < 0);                 // role 1's probe counts (the same value in both lanes)
+            if (!R1) { SNK_COUNT(58); if (com) SNK_COUNT(59); if (offer) SNK_COUNT(60); if ((int32_t)qk < 0) SNK_COUNT(61); }
             if (R1 && com) {                                            // ... its two puts, after role 0's (liblz4's order)
                 tbl[s2] = (uint16_t)(c - 2u);
                 atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u));
