@@ -1264,12 +1264,20 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #define SNK_SPEC_MASKOR \
     "v_alignbit_b32 v89, v89, v88, v109\n\t" \
     "v_or_b32_e32 v113, v113, v89\n\t"
+// opn = the output position after this lane's probe if it is a match: token + literals - back-extension + offset
+#define SNK_SPEC_OPN \
+    "v_min3_u32 v120, v120, %[lit], v111\n\t"           /* back-extension: not beyond the literals, not before the stream start */ \
+    "v_sub_u32_e32 v121, %[lit], v120\n\t" \
+    "v_add3_u32 %[opn], %[op], v121, 3\n\t"
 #define SNK_SPEC_SHADOW(PH) SNK_SPEC_SHADOW_X(PH, "")
 #define SNK_SPEC_SHADOW_X(PH, LOAD2) \
     "global_load_dwordx2 v[106:107], v104, %[arena]\n\t" LOAD2 \
     "v_cndmask_b32_e64 v126, 0, 4, %[sl]\n\t" \
     "v_add_u32_e32 %[nxoff], %[nxoff], v126\n\t" \
     "global_load_dword v108, %[nxoff], %[arena]\n\t" SNK_PADC \
+    SNK_SPEC_OPN                                                /* the last trip's account, here where the wave waits anyway */ \
+    "s_and_b64 %[scm], %[sc], %[sm]\n\t"                        /* (sm holds role 1's bits too: role 1's copies are not used) */ \
+    "s_andn2_b64 %[sc0], %[sc], %[sm]\n\t" \
     "v_lshrrev_b32_e32 v97, 5, %[s2]\n\t"                       /* role 0: put(cur-2), put(cur) -- behind the read, patched in for role 1 */ \
     "v_lshl_add_u32 v97, v97, 2, %[lb]\n\t" \
     "v_lshlrev_b32_e64 v98, %[s2], 1\n\t" \
@@ -1349,29 +1357,25 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "ds_read_u16 %[ns2], v121\n\t" SNK_PADE \
     SNK_SPEC_DEF_B \
     /* this probe's accounting; the masks of the next trip */ \
+    /* the masks of the next trip and the exit test.  Service: the next cursor at the limit (incl. a straddling candidate and 12 equal */ \
+    /* bases: a huge next cursor), or sp -- literal run, budget, back-extension of 4 -- which PRE / the compare above decided for   */ \
+    /* role 0 (a superset of the exact test by the one case of a candidate within 4 bases of the stream start: a needless exit).  */ \
+    /* The account of this probe (opn) is taken in the next trip's load shadow, or below when the loop ends here.                  */ \
     "v_cmp_ne_u32_e64 %[sm], v122, v118\n\t"            /* the last probe that counted was a match: put(cur-2) owed */ \
-    "v_min3_u32 v120, v120, %[lit], v111\n\t" \
-    "v_sub_u32_e32 v121, %[lit], v120\n\t" \
-    "s_and_b64 %[scm], %[sc], %[sm]\n\t" \
-    "s_andn2_b64 %[sc0], %[sc], %[sm]\n\t" \
-    "s_or_b64 %[sm], %[sm], %[r1m]\n\t" \
-    "v_add3_u32 %[opn], %[op], v121, 3\n\t" \
-    "v_add_u32_e32 v123, 11, v120\n\t" \
-    "v_max3_i32 v125, v123, %[lit], v124\n\t" \
-    "v_cmp_lt_i32_e32 vcc, 14, v125\n\t" \
     "v_cmp_ge_u32_e64 %[st], v115, " LIM "\n\t" \
     "s_orn2_b64 %[ss], %[sc], %[r1m]\n\t"               /* role 0, and role 1 when its probe counts */ \
-    "s_or_b64 vcc, vcc, %[st]\n\t" \
-    "s_or_b64 vcc, vcc, %[sp]\n\t" \
+    "s_or_b64 %[sm], %[sm], %[r1m]\n\t" \
+    "s_or_b64 vcc, %[st], %[sp]\n\t" \
     "s_and_b64 vcc, vcc, %[ss]\n\t" \
     "s_cbranch_vccz 1b\n\t" \
+    SNK_SPEC_OPN \
     "s_waitcnt lgkmcnt(0)\n\t"
 #define SNK_SPEC_OPERANDS \
     : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
       [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
-      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), \
-      [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sq] "=&s"(sq), [sp] "=&s"(sp), \
-      [sb] "=&s"(sb), [sc] "=&s"(sc), [ex] "=&s"(ex) \
+      [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), [sq] "+s"(sq), [sc] "+s"(sc), \
+      [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sp] "=&s"(sp), \
+      [sb] "=&s"(sb), [ex] "=&s"(ex) \
     : [lb] "v"(lds_off), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
       [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(DUMMY), \
       [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "v"(0u) \
@@ -1455,7 +1459,7 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         uint32_t ns2 = lut0[(wc >> 4) & 1023u];
         uint32_t opn = op, lit;
         if (R1) op = 0u, opn = 0u;                                              // role 1 keeps no account
-        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sv, ss, st, sq, sp, sb, sc, ex;
+        uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sq = 0, sc = 0, sv, ss, st, sp, sb, ex;   // (sq, sc: nothing to commit in the first trip)
         if (!EXC || !need_mask) {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
