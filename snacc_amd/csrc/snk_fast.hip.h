@@ -1227,8 +1227,17 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #define SNK_SPEC_W0 "4"
 #define SNK_SPEC_W1
 #define SNK_SPEC_CUR "v_add_u32_e32 v104, 2, v127\n\t"      /* this trip's cursor (+ 65536: 16-bit data of role 1's put) */
+// what depends on the cursor alone is computed as soon as the cursor is known, at the loop's bottom where the wave waits
+// for the LUT anyway (and once in front of the loop): cur + 1; cur - 2 in this block (bit 16 set: the patch value of an owed
+// put, and with its low 16 bits the data of put(cur-2)); for role 1 the partner's put(cur) = this cursor - 5 and its put(cur-2)
+#define SNK_SPEC_CURS \
+    "v_add_u32_e32 v112, 1, %[c]\n\t" \
+    "v_add_u32_e32 v102, 0xfffb, %[c]\n\t" \
+    "v_add_u32_e32 v103, 0xfff9, %[c]\n\t" \
+    "v_add_u32_e32 v127, 0xfffe, %[c]\n\t"
 #define SNK_SPEC_TABLE \
     "s_mov_b64 %[ex], exec\n\t"                         /* the lanes of the loop */ \
+    SNK_SPEC_CURS \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(" SNK_SPEC_W0 ")\n\t"            /* the slots of cur and cur-2 (behind them: role 1's four put operations) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
@@ -1238,16 +1247,12 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_lshlrev_b32_e64 v93, %[s1], 1\n\t" \
     "v_cndmask_b32_e64 v99, v93, 0, %[r1m]\n\t"         /* role 1 only reads */ \
     "ds_or_rtn_b32 v94, v92, v99 offset:1792\n\t" SNK_PADA \
-    "v_add_u32_e32 v112, 1, %[c]\n\t" \
     SNK_SPEC_W1 \
     "v_cndmask_b32_e64 %[s2], %[dm], %[ns2], %[sm]\n\t" /* nothing owed: the unused slot (role 1: always owed) */ \
-    "v_add_u32_e32 v102, 0xfffb, %[c]\n\t"              /* role 1: the partner's put(cur) = this cursor - 5 */ \
-    "v_add_u32_e32 v103, 0xfff9, %[c]\n\t"              /* ... its put(cur-2) */ \
     "v_lshl_or_b32 v100, %[s2], 16, %[s1]\n\t"          /* both slots, for the partner */ \
-    "v_add_u32_e32 v127, 0xfffe, %[c]\n\t"              /* cur - 2 in this block: role 1's patch, and (low 16 bits) the data of put(cur-2) */ \
-    "v_mov_b32_dpp v101, v100 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
     "v_cmp_eq_u32_e32 vcc, %[s2], %[s1]\n\t" \
-    "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t" \
+    "v_lshl_add_u32 v95, %[s2], 1, %[lb]\n\t"           /* (two instructions between the write of v100 and its DPP read) */ \
+    "v_mov_b32_dpp v101, v100 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
     "v_cmp_eq_u16_sdwa %[ss], %[s1], v101 src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
     "v_cmp_eq_u16_sdwa %[st], %[s1], v101 src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
     "s_and_b64 %[ss], %[ss], %[r1m]\n\t" \
@@ -1356,6 +1361,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_and_b32_e32 v121, 0x7fe, v121\n\t" \
     "ds_read_u16 %[ns2], v121\n\t" SNK_PADE \
     SNK_SPEC_DEF_B \
+    SNK_SPEC_CURS \
     /* this probe's accounting; the masks of the next trip */ \
     /* the masks of the next trip and the exit test.  Service: the next cursor at the limit (incl. a straddling candidate and 12 equal */ \
     /* bases: a huge next cursor), or sp -- literal run, budget, back-extension of 4 -- which PRE / the compare above decided for   */ \
