@@ -74,6 +74,9 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   (full table / compact 1024 slots / compact 2048 slots)
  *   "bytes_compact" -1 auto (default) / 0 never: compact table of the byte kernel when the
  *                   resident sequences use <= 2048 distinct 5-byte hashes (set before upload)
+ *   "bytes_spec"    0 (default) / 1: LDS byte kernels on the slot stream with two lanes per chain (the second lane probes
+ *                   5 bytes ahead and counts when the first lane's match ends there; exact).  Measured without gain
+ *                   (DESIGN.md section 6.0); kept for experiments.
  *   "bytes_gt"      byte kernels with their tables in global memory, one chain per lane: waves per workgroup (1..8);
  *                   0 = tables in LDS; -1 (default) = 4 for the full table once the launch has more jobs than two rounds
  *                   of the LDS kernel, LDS otherwise (the compact tables are faster in LDS).  "bytes_gt_wgs": workgroups
