@@ -188,6 +188,15 @@ void snk_free(void *p);
 /* Ingest + snk_upload in one call: the sequence bytes never enter the caller's language runtime. */
 int snk_upload_fasta(snk_ctx *ctx, int n, const char *const *paths, int reverse_complement, int n_threads);
 
+/* ---- CSV text of the distance matrix -----------------------------------------
+ * The fields of `rows` x `cols` float64 values as the reference's DataFrame.to_csv writes them
+ * (ref:snacc/cli.py:138-142: Python's repr of a float -- shortest round-trip digits, exponent form below
+ * 1e-4 and from 1e16 on, ".0" on whole numbers, NaN as an empty field), joined by ','.  Row r is written
+ * to out + r * stride (stride >= cols * SNK_CSV_FIELD_MAX bytes), len[r] = its length; no terminator, no
+ * line end.  Host code only (n_threads host threads); the caller adds the label column and line ends. */
+#define SNK_CSV_FIELD_MAX 25
+int snk_csv_rows_f64(const double *m, uint64_t rows, uint64_t cols, char *out, uint64_t stride, uint32_t *len, int n_threads);
+
 /* ---- gzip / zlib sizes -----------------------------------------------------
  * Replace, for the batched path, the codec calls of ref:snacc/pairwise_ncd.py:73-74
  * (gzip.compress -> deflate level 9) and :77-78 (zlib.compress -> deflate level 6) on the resident

@@ -53,11 +53,58 @@ def write_matrix_csv(files, matrix, output):
     minimal quoting, ``os.linesep`` line ends.  Written directly: building the
     reference's 1 M-row long-form DataFrame and pivoting it is the slow part at N >= 1024;
     ``tests/test_host_logic.py`` checks byte equality with the pandas route."""
+    order = sorted(range(len(files)), key=lambda i: files[i])
+    labels = [str(files[i]) for i in order]
+    m = np.ascontiguousarray(np.asarray(matrix, dtype=np.float64)[np.ix_(order, order)])
+    bodies = _csv_row_bodies(m)
+    if bodies is None:
+        return write_matrix_csv_python(files, matrix, output)
+    import csv
+    import io
+    sio = io.StringIO()
+    wr = csv.writer(sio, lineterminator=os.linesep, quoting=csv.QUOTE_MINIMAL)
+    wr.writerow(["file"] + labels)
+    eol = os.linesep.encode()
+    with open(output, "wb") as f:
+        f.write(sio.getvalue().encode("utf-8"))
+        for label, body in zip(labels, bodies):
+            sio.seek(0); sio.truncate()
+            wr.writerow([label, ""])                         # "label," with the quoting the csv module gives the label
+            f.write(sio.getvalue()[: -len(os.linesep)].encode("utf-8"))
+            f.write(body)
+            f.write(eol)
+
+
+def _csv_row_bodies(m):
+    """The float fields of every row, joined by ',', formatted by the library's host code (Python's repr of a float,
+    NaN as an empty field: `snk_csv_rows_f64`) -- formatting a million floats in Python costs more than a sixth of the
+    whole `snacc <1024 genomes> -c lz4` run.  None when the library cannot be loaded (the Python statement
+    :func:`write_matrix_csv_python` is then used; the tests hold the two and the pandas route equal)."""
+    try:
+        from . import hip_backend
+        lib = hip_backend.load()
+    except Exception:                                        # noqa: BLE001  (no library: the Python statement)
+        return None
+    rows, cols = m.shape
+    if rows == 0 or cols == 0:
+        return [b""] * rows
+    stride = cols * 25                                       # SNK_CSV_FIELD_MAX per value
+    out = np.empty(rows * stride, dtype=np.uint8)
+    lens = np.zeros(rows, dtype=np.uint32)
+    rc = lib.snk_csv_rows_f64(m.ctypes.data, rows, cols, out.ctypes.data, stride, lens.ctypes.data,
+                              hip_backend.default_threads())
+    if rc != 0:
+        return None
+    return [out[r * stride: r * stride + int(lens[r])].tobytes() for r in range(rows)]
+
+
+def write_matrix_csv_python(files, matrix, output):
+    """The Python statement of :func:`write_matrix_csv` (csv module + ``repr``); its checker, and the route without the library."""
     import csv
     order = sorted(range(len(files)), key=lambda i: files[i])
     labels = [str(files[i]) for i in order]
     m = np.asarray(matrix, dtype=np.float64)[np.ix_(order, order)]
-    with open(output, "w", newline="") as f:
+    with open(output, "w", newline="", encoding="utf-8") as f:
         wr = csv.writer(f, lineterminator=os.linesep, quoting=csv.QUOTE_MINIMAL)
         wr.writerow(["file"] + labels)
         for label, row in zip(labels, m.tolist()):

@@ -13,6 +13,8 @@
 #include "snacc_hip.h"
 
 #include <atomic>
+#include <charconv>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -125,6 +127,48 @@ thread_local std::string g_fasta_error;
 
 } // namespace
 
+
+// ---- CSV text of the NCD matrix ---------------------------------------------------------------------
+// One field as pandas' to_csv writes a float64 (ref:snacc/cli.py:138-142), i.e. Python's repr: the shortest digit string that
+// round-trips (std::to_chars gives the same digits: shortest, and the closest to the value among the shortest), exponent
+// form when the decimal exponent is < -4 or >= 16 (at least two exponent digits, always a sign), else positional with
+// ".0" for whole numbers; "inf" / "-inf"; NaN is an empty field.  At most 24 bytes.
+static size_t snk_repr_f64(double v, char *out)
+{
+    if (v != v) return 0;
+    char b[40];
+    char *o = out;
+    if (v == 0.0) { if (std::signbit(v)) *o++ = '-'; memcpy(o, "0.0", 3); return (size_t)(o + 3 - out); }
+    if (v > 1.7976931348623157e308 || v < -1.7976931348623157e308) { if (v < 0) *o++ = '-'; memcpy(o, "inf", 3); return (size_t)(o + 3 - out); }
+    const std::to_chars_result r = std::to_chars(b, b + sizeof b, v, std::chars_format::scientific);
+    // b = [-]d[.ddd]e[+-]XX[X]
+    const char *p = b;
+    if (*p == '-') { *o++ = '-'; ++p; }
+    const char *e = p;
+    while (e < r.ptr && *e != 'e') ++e;
+    char digits[24]; int nd = 0;
+    for (const char *q = p; q < e; ++q) if (*q != '.') digits[nd++] = *q;
+    int ex = 0; { const char *q = e + 1; const bool neg = (*q == '-'); ++q; for (; q < r.ptr; ++q) ex = ex * 10 + (*q - '0'); if (neg) ex = -ex; }
+    if (ex < -4 || ex >= 16) {                                   // d[.ddd]e[+-]XX
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, digits + 1, (size_t)(nd - 1)); o += nd - 1; }
+        *o++ = 'e'; *o++ = ex < 0 ? '-' : '+';
+        int ax = ex < 0 ? -ex : ex;
+        char t[4]; int nt = 0; do { t[nt++] = (char)('0' + ax % 10); ax /= 10; } while (ax);
+        if (nt < 2) t[nt++] = '0';
+        while (nt) *o++ = t[--nt];
+    } else if (ex < 0) {                                         // 0.000ddd
+        *o++ = '0'; *o++ = '.';
+        for (int k = 0; k < -ex - 1; ++k) *o++ = '0';
+        memcpy(o, digits, (size_t)nd); o += nd;
+    } else {                                                     // ddd[.ddd] / ddd000.0
+        const int ip = ex + 1;                                   // digits in front of the point
+        if (nd <= ip) { memcpy(o, digits, (size_t)nd); o += nd; for (int k = nd; k < ip; ++k) *o++ = '0'; *o++ = '.'; *o++ = '0'; }
+        else { memcpy(o, digits, (size_t)ip); o += ip; *o++ = '.'; memcpy(o, digits + ip, (size_t)(nd - ip)); o += nd - ip; }
+    }
+    return (size_t)(o - out);
+}
+
 extern "C" {
 
 const char *snk_fasta_last_error(void) { return g_fasta_error.c_str(); }
@@ -198,6 +242,31 @@ int snk_upload_fasta(snk_ctx *ctx, int n, const char *const *paths, int reverse_
     for (auto p : outs) free(p);
     if (rc) g_fasta_error = snk_last_error(ctx);
     return rc;
+}
+
+int snk_csv_rows_f64(const double *m, uint64_t rows, uint64_t cols, char *out, uint64_t stride, uint32_t *len, int n_threads)
+{
+    if ((rows && cols && (!m || !out)) || (rows && !len) || stride < cols * SNK_CSV_FIELD_MAX) return SNK_E_ARG;
+    std::atomic<uint64_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const uint64_t r = next.fetch_add(1);
+            if (r >= rows) return;
+            char *o = out + r * stride;
+            const double *v = m + r * cols;
+            for (uint64_t c = 0; c < cols; ++c) {
+                if (c) *o++ = ',';
+                o += snk_repr_f64(v[c], o);
+            }
+            len[r] = (uint32_t)(o - (out + r * stride));
+        }
+    };
+    const int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    std::vector<std::thread> ts;
+    for (int t = 1; t < nt; ++t) ts.emplace_back(work);
+    work();
+    for (auto &t : ts) t.join();
+    return SNK_OK;
 }
 
 } // extern "C"

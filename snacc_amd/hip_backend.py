@@ -22,7 +22,7 @@ EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
     "snk_upload", "snk_num_sequences", "snk_lengths", "snk_num_packed", "snk_fast_chains", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
     "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms", "snk_pairs_ms_log",
-    "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta",
+    "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta", "snk_csv_rows_f64",
     "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_pairs_device", "snk_deflate_last_ms",
 )
 
@@ -126,6 +126,8 @@ def load():
     L.snk_free.argtypes = [vp]
     L.snk_upload_fasta.restype = i32
     L.snk_upload_fasta.argtypes = [vp, i32, vp, i32, i32]
+    L.snk_csv_rows_f64.restype = i32
+    L.snk_csv_rows_f64.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, vp, ctypes.c_uint64, vp, i32]
     L.snk_deflate_prepare.restype = i32
     L.snk_deflate_prepare.argtypes = [vp, i32]
     L.snk_deflate_singles.restype = i32

@@ -10,7 +10,7 @@ import pytest
 from conftest import materialise_cli_set
 from snacc_amd import compressed_size, compute_distance
 from snacc_amd import fasta
-from snacc_amd.cli import discover_files, write_matrix_csv, write_matrix_csv_pandas
+from snacc_amd.cli import discover_files, write_matrix_csv, write_matrix_csv_pandas, write_matrix_csv_python
 from snacc_amd.matrix import GETSIZEOF_OVERHEAD, ncd_matrix
 from snacc_amd.pairwise_ncd import extract_sequences
 
@@ -164,10 +164,39 @@ def test_direct_csv_writer_equals_pandas(tmp_path):
     files[3] = Path('/data/we"ird/q.fa')
     files[11] = Path("/data/x/a.b")           # Path order != string order against /data/x/a/...
     files[12] = Path("/data/x/a/b")
-    a, b = tmp_path / "direct.csv", tmp_path / "pandas.csv"
-    write_matrix_csv(files, m, a)
+    m[8, 8] = float("nan"); m[9, 1] = 0.0; m[9, 2] = -0.0; m[9, 3] = 1e16; m[9, 4] = 9999999999999998.0; m[9, 5] = 1e-4
+    m[9, 6] = 9.999e-5; m[9, 7] = 1.7976931348623157e308; m[9, 8] = 2.2250738585072014e-308; m[9, 9] = 100.0; m[9, 10] = 0.5
+    a, b, c = tmp_path / "direct.csv", tmp_path / "pandas.csv", tmp_path / "python.csv"
+    write_matrix_csv(files, m, a)               # the library's formatter (snk_csv_rows_f64) when the library loads
     write_matrix_csv_pandas(files, m, b)
+    write_matrix_csv_python(files, m, c)        # the Python statement (csv module + repr)
     assert a.read_bytes() == b.read_bytes()
+    assert c.read_bytes() == b.read_bytes()
+
+
+def test_native_float_fields_equal_python_repr():
+    """snk_csv_rows_f64 writes every float64 as Python's repr does (what pandas' to_csv writes, ref:snacc/cli.py:138-142):
+    random doubles over the whole exponent range, the NCD range, powers of ten around both notation switches, subnormals,
+    whole numbers, infinities; NaN is an empty field."""
+    import struct
+    from snacc_amd.cli import _csv_row_bodies
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 2 ** 63, 200000, dtype=np.int64).astype(np.uint64) | (rng.integers(0, 2, 200000).astype(np.uint64) << np.uint64(63))
+    vals = np.frombuffer(bits.tobytes(), dtype=np.float64).copy()
+    vals = vals[np.isfinite(vals)]
+    extra = [10.0 ** k for k in range(-30, 31)] + [1.5 * 10.0 ** k for k in range(-8, 20)] + [float(k) for k in range(-5, 40)]
+    extra += [0.1 + 0.2, 1 / 3, 2 / 3, 5e-324, 2.5e-323, float("inf"), float("-inf"), 123456789012345680.0, 1e15 + 0.5, 0.00010000000000000002]
+    ncd = 0.9 + 0.2 * rng.random(100000)
+    allv = np.concatenate([vals, np.array(extra), ncd, -ncd[:1000]])
+    cols = 1000
+    n = (len(allv) // cols) * cols
+    m = np.ascontiguousarray(allv[:n].reshape(-1, cols))
+    m[0, 3] = float("nan")
+    bodies = _csv_row_bodies(m)
+    assert bodies is not None, "libsnacc_hip.so must load (host code: no GPU needed)"
+    for r, body in enumerate(bodies):
+        exp = ",".join("" if v != v else repr(v) for v in m[r].tolist())
+        assert body.decode() == exp, (r, [(a, b) for a, b in zip(body.decode().split(","), exp.split(",")) if a != b][:3])
 
 
 def test_cli_gzip_flow_matches_reference_cli(golden, oracle_mod, tmp_path, monkeypatch):
