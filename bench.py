@@ -43,7 +43,7 @@ LCG_C = 1442695040888963407
 # The issue-slot floor of a trip = (instructions per wave-trip, from the committed SQ counters of this kernel) x 4.2; what
 # the measured trip has on top of it is exposed waiting (L1 window, LDS / VMEM issue stalls).
 ISSUE_MODEL = {"cycles_per_issue_slot": 4.2, "waitcnt_and_branch_slots_per_trip": 5, "chains_per_cu": 84, "cus": 256, "clock_hz": 2.4e9}
-PROFILE_ROUNDS = ("r03", "r02")          # newest committed summary first
+PROFILE_ROUNDS = ("r04", "r03", "r02")   # newest committed summary first
 
 
 def lcg_genomes_torch(n_genomes, length, seed0, device):
@@ -79,7 +79,10 @@ def pmc_traffic(rows, n, length, codec="lz4", data="lcg"):
     (profiles/rNN_pmc_traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE
     doubled per the gfx950 calibration of MI355X_MICROARCH.md; the file names the commit it was taken at).
     Only valid for the launch shape and data set it was collected on; None otherwise."""
-    t, src = _profile("pmc_traffic" if codec == "lz4" else f"pmc_traffic_{codec}")
+    stem = "pmc_traffic" if codec == "lz4" else f"pmc_traffic_{codec}"
+    if data != "lcg":
+        stem += f"_{data}"
+    t, src = _profile(stem)
     try:
         if t and (t["rows"], t["genomes"], t["length"]) == (rows, n, length) and t.get("data", "lcg") == data:
             return t["hbm_bytes_per_launch"], f"{src} @ {t.get('collected_at_commit', '?')}"
@@ -173,6 +176,83 @@ def markov_genomes_torch(n_genomes, length, device, seed=20261004):
                 s[p + int(rng.integers(0, n))] = b"ACGT"[int(rng.integers(0, 4))]
         res.append(s)
     return res
+
+
+def softmask_genomes(genomes, pct, seed=11):
+    """Secondary data set: the genomes with `pct` % of their bases in lower case, in stretches of 300 - 700 bases (soft-masked
+    repeats as genome assemblies carry them; the rule of tools/gpu_exc.py `softPCT`).  The 2-bit kernel serves such sets with
+    its other-case machinery."""
+    out = []
+    for g, a in enumerate(genomes):
+        rng = np.random.default_rng(seed + g)
+        a = a.copy()
+        n = len(a)
+        for s0 in rng.integers(0, max(n - 600, 1), max(1, n * pct // 100 // 500)):
+            a[s0:s0 + int(rng.integers(300, 700))] |= 0x20
+        out.append(a)
+    return out
+
+
+def secondary_leg(name, genomes, codec, local_rank, dev, R, steps, opts, data_key):
+    """One short leg behind the headline region, under the same clock: upload, 1 warm-up launch, `steps` timed launches of R
+    rows x N columns on a fresh context, a spot check of the last tile against the oracle, the roofline figures."""
+    import torch
+    from snacc_amd.hip_backend import HipContext
+    N, L = len(genomes), len(genomes[0])
+    deflate = codec != "lz4"
+    t0 = time.perf_counter()
+    ctx = HipContext(local_rank, **dict(opts, **({"defer_singles": 1} if deflate else {})))
+    try:
+        ctx.upload(genomes)
+        if deflate:
+            ctx.deflate_singles(codec)
+        t_setup = time.perf_counter() - t0
+        stream = torch.cuda.Stream(dev)
+        tile = torch.zeros((R, N), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        kern_ms = []
+
+        def launch(r0):
+            if deflate:
+                ctx.deflate_pairs_device(codec, r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+                kern_ms.append(ctx.deflate_last_ms())
+            else:
+                ctx.pairs_device(r0, r0 + R, tile.data_ptr(), stream.cuda_stream)
+
+        launch(0)
+        ctx.sync(stream.cuda_stream)
+        kern_ms.clear()
+        if not deflate:
+            ctx.pairs_ms_log()
+        last_r0 = 0
+        t0 = time.perf_counter()
+        for k in range(steps):
+            last_r0 = ((k + 1) * R) % max(N - R + 1, 1)
+            launch(last_r0)
+        ctx.sync(stream.cuda_stream)
+        elapsed = time.perf_counter() - t0
+        if not deflate:
+            kern_ms = ctx.pairs_ms_log()
+        host = tile.cpu().numpy().view(np.uint32)
+    finally:
+        ctx.close()
+    import oracle
+    if deflate:
+        from oracle import deflate as dfl_oracle
+        lvl = {"gzip": 9, "zlib": 6}[codec]
+        parity = all(int(host[0, j]) == dfl_oracle.raw_size(genomes[last_r0], genomes[j], lvl) for j in (0, 1))
+    else:
+        parity = all(int(host[i, j]) == oracle.lz4f_size_pair(genomes[last_r0 + i], genomes[j])
+                     for i, j in ((0, 0), (0, N - 1), (R - 1, 1), (R // 2, N // 2)))
+    kavg = float(np.mean(kern_ms)) if len(kern_ms) else elapsed / max(steps, 1) * 1e3
+    alg = R * N * (2 * L + 4)
+    achieved = alg / (kavg * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(R, N, L, codec, data_key)
+    return {"pair_compressions_per_s": R * N * steps / elapsed, "ncd_per_s": R * N * steps / elapsed / 2.0,
+            "kernel_ms_avg": kavg, "steps": steps, "rows_per_step": R, "setup_s": round(t_setup, 3),
+            "parity_spot_check": bool(parity), "codec": codec, "data": name,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": traffic, "traffic_source": traffic_src}}
 
 
 def write_fasta_files(directory, genomes, width=80):
@@ -355,6 +435,9 @@ def main():
                     help="lcg (default, the metric's data set: i.i.d. uniform ACGT); related: 2 %% mutants of 16 ancestors; "
                          "markov: order-3 Markov chain + tandem repeats (secondary data sets, SURVEY.md 8d)")
     ap.add_argument("--no-cli-wall", action="store_true", help="skip the end-to-end CLI run (FASTA files -> CSV)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short secondary legs behind the headline region (markov / related / soft-masked 5 %% data, gzip, zlib)")
+    ap.add_argument("--secondary-steps", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -519,13 +602,20 @@ def main():
     # ---- the metric's second half, MEASURED: one full N x N matrix (strong scaling over the ranks) ----
     matrix = None
     if not args.no_matrix:
-        from snacc_amd.matrix import ncd_matrix
+        from snacc_amd.matrix import ncd_matrix_raw
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
         fence()
         m0 = time.perf_counter()
-        ctx2 = HipContext(local_rank, **opts)
+        # phase A on demand for a sharded run (every rank: its own rows; the sizes ride on the tile gathers) and for gzip /
+        # zlib (never needed); a single rank computes it as part of the upload
+        ctx2 = HipContext(local_rank, **dict(opts, **({"defer_singles": 1} if (deflate or world > 1) else {})))
         ctx2.upload(genomes)
-        singles = (ctx2.deflate_singles(args.codec) if deflate else ctx2.singles()).astype(np.int64) + 33
+        stages = ctx2.upload_times()
+        singles = None
+        if deflate:
+            singles = ctx2.deflate_singles(args.codec)
+        elif world == 1:
+            singles = ctx2.singles()
         m1 = time.perf_counter()
         if world == 1:
             pairs = ctx2.deflate_pairs(args.codec) if deflate else ctx2.pairs()     # (deflate sizes include the wrapper bytes)
@@ -534,9 +624,9 @@ def main():
         elif deflate:
             pairs = sdist.all_pairs_deflate_hip(ctx2, N, args.codec, lengths=ctx2.lengths())
         else:
-            pairs = sdist.all_pairs_hip(ctx2, N, lengths=ctx2.lengths())
+            pairs, singles = sdist.all_pairs_hip(ctx2, N, lengths=ctx2.lengths(), with_singles=True)
         m2 = time.perf_counter()
-        ncd = ncd_matrix(singles, pairs.astype(np.int64) + 33) if (rank == 0 and pairs is not None) else None
+        ncd = ncd_matrix_raw(singles, pairs) if (rank == 0 and pairs is not None) else None
         m3 = time.perf_counter()
         ctx2.close()
         wall = m3 - m0
@@ -546,6 +636,10 @@ def main():
             wall = float(tmax.item())
         if pairs is not None:
             matrix = {"matrix_wall_s": wall, "upload_and_singles_s": m1 - m0, "pairs_and_gather_s": m2 - m1, "ncd_assembly_s": m3 - m2,
+                      # what does not shrink with more ranks: every rank uploads all sequences (and, alone, runs phase A of all of
+                      # them), rank 0 assembles the matrix.  Under --gpus N phase A is per owner and sits in pairs_and_gather_s.
+                      "fixed_s": (m1 - m0) + (m3 - m2), "upload_stages_s": {k: round(v, 4) for k, v in stages.items()},
+                      "strong_pair_compressions_per_s": (N * N + N) / wall, "strong_ncd_per_s": (N * N + N) / wall / 2.0,
                       "ncds": N * (N + 1) // 2, "symmetric": bool(ncd is None or np.array_equal(ncd, ncd.T)),
                       "what": "upload + singles/snapshots + all N rows (split over the ranks) + gather + D2H + float64 NCD matrix, one run"}
 
@@ -580,6 +674,28 @@ def main():
             cli_run = cli_wall(genomes, args.codec, os.environ.get("TMPDIR", "/tmp"))
         except Exception as e:                              # noqa: BLE001  (an extra of the line: e.g. no room for the FASTA files)
             cli_run = {"cli_wall_s": None, "error": repr(e)}
+
+    # ---- secondary legs, under the same clock as the headline (after its timed region; the headline keys are untouched) ----
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and args.codec == "lz4" and args.data == "lcg":
+        secondary = {}
+        ctx.close()                                        # the headline context's arenas: room for the legs' own
+        legs = [("markov", lambda: markov_genomes_torch(N, L, dev), "lz4", "markov"),
+                ("related", lambda: lcg_related_torch(N, L, dev), "lz4", "related"),
+                ("softmask5", lambda: softmask_genomes(genomes, 5), "lz4", "softmask5"),
+                ("gzip", lambda: genomes, "gzip", "lcg"),
+                ("zlib", lambda: genomes, "zlib", "lcg")]
+        for name, make, codec, key in legs:
+            t_leg = time.perf_counter()
+            try:
+                gs = make()
+                t_made = time.perf_counter() - t_leg
+                secondary[name] = secondary_leg(name, gs, codec, local_rank, dev, R, args.secondary_steps, opts, key)
+                secondary[name]["generate_s"] = round(t_made, 2)
+                del gs
+            except Exception as e:                         # noqa: BLE001  (an extra of the line)
+                secondary[name] = {"error": repr(e)}
+            secondary[name]["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
 
     if rank == 0:
         if args.mode == "strong" and matrix:
@@ -631,6 +747,10 @@ def main():
             "cycle_account": cycle_account() if args.codec == "lz4" else None,
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": parity, "allgather_check": gather_ok,
+            "secondary": secondary,
+            # the strong-scaling figure beside the weak one (the driver's --gpus N runs read `value`; this is the whole matrix, one run)
+            "strong": ({"pair_compressions_per_s": matrix["strong_pair_compressions_per_s"], "ncd_per_s": matrix["strong_ncd_per_s"],
+                        "matrix_wall_s": matrix["matrix_wall_s"], "fixed_s": matrix["fixed_s"], "n_gpus": world} if matrix else None),
             "setup_s": {"generate": round(t_gen, 2), "upload_and_singles": round(t_upload, 2)},
         }
         print(json.dumps(line), flush=True)

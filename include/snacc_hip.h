@@ -101,7 +101,15 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *   "deflate_norestart" 1 = gzip / zlib: a pair job parses x from its first byte instead of restarting from x's
  *                   stored stream shortly before the seam (testing; same results)
  *   "content_size"  1 = add the 8-byte content-size field to every frame
- *                   (py-lz4framed builds that set it)        */
+ *                   (py-lz4framed builds that set it)
+ *   "fast_asm"      1 (default) = the hand-scheduled steady loop of the 2-bit kernel; 0 = its C++ statement (cross-checks)
+ *   "fast_spec"     1 (default) = two lanes per chain in the 2-bit kernel's steady loop (snk_fast_steady_spec: the second
+ *                   lane probes 5 bases ahead; exact); 0 = one lane per chain
+ *   "defer_singles" 1 = snk_upload / snk_upload_fasta leave phase A (single sizes + prefix snapshots) to the calls that
+ *                   need it: snk_singles / snk_singles_rows for the rows asked for, the snk_pairs* calls for the rows
+ *                   (prefixes) they compute.  A rank of a row-sharded run thus computes its own rows only, and a
+ *                   gzip / zlib run (snk_deflate_*) never runs the lz4 pass.  Default 0: phase A of every sequence
+ *                   is part of the upload.        */
 int snk_set_option(snk_ctx *ctx, const char *key, long value);
 
 /* Replaces the per-task FASTA->bytes hand-off of ref:snacc/pairwise_ncd.py:59-69.
@@ -127,6 +135,17 @@ int snk_num_compact_hashes(const snk_ctx *ctx);
 
 /* Phase A (ref:snacc/cli.py:108-116): sizes[i] = len(lz4framed.compress(seq_i)). */
 int snk_singles(snk_ctx *ctx, uint32_t *sizes /* [n_seq], host */);
+
+/* The same for the sequences [row_begin, row_end): sizes[i - row_begin].  With the option "defer_singles" phase A of
+ * these rows (single sizes + the prefix snapshots their pair launches start from) runs now if it has not yet; a rank of
+ * a row-sharded run asks for its own rows only and sends the sizes along with its tiles. */
+int snk_singles_rows(snk_ctx *ctx, int row_begin, int row_end, uint32_t *sizes /* [row_end - row_begin], host */);
+
+/* Host wall time (ms) of the stages of the last snk_upload / snk_upload_fasta on `ctx`, each ended by a stream
+ * synchronisation: ms[0] device arena + host-to-device copies, [1] classification (exception granules, runs),
+ * [2] 2-bit pack (+ class arena), [3] hash sets + slot stream of the byte kernels, [4] per-sequence tables,
+ * [5] phase A (singles + snapshots; 0 when deferred), [6] the whole call.  Up to `cap` values; returns 7. */
+int snk_upload_times(const snk_ctx *ctx, double *ms, int cap);
 
 /* Phase B (ref:snacc/cli.py:120-129) for rows [row_begin, row_end):
  *   sizes[(i-row_begin)*n_seq + j] = len(lz4framed.compress(seq_i + seq_j)).
@@ -196,6 +215,13 @@ int snk_upload_fasta(snk_ctx *ctx, int n, const char *const *paths, int reverse_
  * line end.  Host code only (n_threads host threads); the caller adds the label column and line ends. */
 #define SNK_CSV_FIELD_MAX 25
 int snk_csv_rows_f64(const double *m, uint64_t rows, uint64_t cols, char *out, uint64_t stride, uint32_t *len, int n_threads);
+
+/* ---- NCD matrix from the integer sizes (ref:snacc/cli.py:131-136, ref:snacc/pairwise_ncd.py:93-111) ------------
+ * out[i*n + j] = compute_distance(S_i, S_j, P_ij, P_ji) with S = singles + overhead and P = pairs + overhead
+ * (overhead = sys.getsizeof(b"") = 33 plus, for gzip / zlib, nothing: their wrapper bytes are in the sizes already):
+ * (min(P_ij, P_ji) - min(S_i, S_j)) / max(S_i, S_j), integer arithmetic and one float64 division -- bit-equal to the
+ * reference's Python.  Host code only (n_threads host threads); `pairs` is the n x n row-major array of snk_pairs. */
+int snk_ncd_matrix_u32(const uint32_t *singles, const uint32_t *pairs, uint64_t n, uint32_t overhead, double *out, int n_threads);
 
 /* ---- gzip / zlib sizes -----------------------------------------------------
  * Replace, for the batched path, the codec calls of ref:snacc/pairwise_ncd.py:73-74

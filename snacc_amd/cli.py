@@ -22,7 +22,7 @@ import numpy as np
 import pandas as pd
 from tqdm import tqdm
 
-from .matrix import GETSIZEOF_OVERHEAD, ncd_matrix
+from .matrix import GETSIZEOF_OVERHEAD, ncd_matrix, ncd_matrix_raw
 from .pairwise_ncd import blob_name, compressed_size, compute_distance, extract_sequences
 from .version import __version__
 
@@ -56,8 +56,8 @@ def write_matrix_csv(files, matrix, output):
     order = sorted(range(len(files)), key=lambda i: files[i])
     labels = [str(files[i]) for i in order]
     m = np.ascontiguousarray(np.asarray(matrix, dtype=np.float64)[np.ix_(order, order)])
-    bodies = _csv_row_bodies(m)
-    if bodies is None:
+    fmt = _csv_row_formatter()
+    if fmt is None:
         return write_matrix_csv_python(files, matrix, output)
     import csv
     import io
@@ -65,37 +65,65 @@ def write_matrix_csv(files, matrix, output):
     wr = csv.writer(sio, lineterminator=os.linesep, quoting=csv.QUOTE_MINIMAL)
     wr.writerow(["file"] + labels)
     eol = os.linesep.encode()
-    with open(output, "wb") as f:
-        f.write(sio.getvalue().encode("utf-8"))
-        for label, body in zip(labels, bodies):
-            sio.seek(0); sio.truncate()
-            wr.writerow([label, ""])                         # "label," with the quoting the csv module gives the label
-            f.write(sio.getvalue()[: -len(os.linesep)].encode("utf-8"))
-            f.write(body)
-            f.write(eol)
+    try:
+        with open(output, "wb") as f:
+            f.write(sio.getvalue().encode("utf-8"))
+            # the float fields come from the library CSV_CHUNK_ROWS rows at a time, into one reused buffer: the text of the
+            # whole matrix (25 bytes per value) is never held at once
+            for r0 in range(0, len(labels), CSV_CHUNK_ROWS):
+                bodies = fmt(m[r0:r0 + CSV_CHUNK_ROWS])
+                if bodies is None:
+                    raise MemoryError("snk_csv_rows_f64 failed")
+                for label, body in zip(labels[r0:r0 + CSV_CHUNK_ROWS], bodies):
+                    sio.seek(0); sio.truncate()
+                    wr.writerow([label, ""])                 # "label," with the quoting the csv module gives the label
+                    f.write(sio.getvalue()[: -len(os.linesep)].encode("utf-8"))
+                    f.write(body)
+                    f.write(eol)
+    except MemoryError:                                      # no room for the staging buffer: the row-by-row Python statement
+        return write_matrix_csv_python(files, matrix, output)
 
 
-def _csv_row_bodies(m):
-    """The float fields of every row, joined by ',', formatted by the library's host code (Python's repr of a float,
-    NaN as an empty field: `snk_csv_rows_f64`) -- formatting a million floats in Python costs more than a sixth of the
-    whole `snacc <1024 genomes> -c lz4` run.  None when the library cannot be loaded (the Python statement
-    :func:`write_matrix_csv_python` is then used; the tests hold the two and the pandas route equal)."""
+#: rows of the matrix formatted per call of the library (one reused staging buffer of rows x cols x 25 bytes)
+CSV_CHUNK_ROWS = 256
+
+
+def _csv_row_formatter():
+    """A function `fmt(rows_of_m) -> list of bytes`: the float fields of each row joined by ',', formatted by the library's
+    host code (Python's repr of a float, NaN as an empty field: `snk_csv_rows_f64`) -- formatting a million floats in
+    Python costs more than a sixth of the whole `snacc <1024 genomes> -c lz4` run.  None when the library cannot be loaded
+    (the Python statement :func:`write_matrix_csv_python` is then used; the tests hold the two and the pandas route
+    equal).  The staging buffer is allocated once, for CSV_CHUNK_ROWS rows, and reused."""
     try:
         from . import hip_backend
         lib = hip_backend.load()
     except Exception:                                        # noqa: BLE001  (no library: the Python statement)
         return None
-    rows, cols = m.shape
-    if rows == 0 or cols == 0:
-        return [b""] * rows
-    stride = cols * 25                                       # SNK_CSV_FIELD_MAX per value
-    out = np.empty(rows * stride, dtype=np.uint8)
-    lens = np.zeros(rows, dtype=np.uint32)
-    rc = lib.snk_csv_rows_f64(m.ctypes.data, rows, cols, out.ctypes.data, stride, lens.ctypes.data,
-                              hip_backend.default_threads())
-    if rc != 0:
-        return None
-    return [out[r * stride: r * stride + int(lens[r])].tobytes() for r in range(rows)]
+    state = {}
+
+    def fmt(m):
+        rows, cols = m.shape
+        if rows == 0 or cols == 0:
+            return [b""] * rows
+        stride = cols * 25                                   # SNK_CSV_FIELD_MAX per value
+        if state.get("cap", 0) < rows * stride:
+            state["out"] = np.empty(rows * stride, dtype=np.uint8)
+            state["cap"] = rows * stride
+        out = state["out"]
+        m = np.ascontiguousarray(m)
+        lens = np.zeros(rows, dtype=np.uint32)
+        rc = lib.snk_csv_rows_f64(m.ctypes.data, rows, cols, out.ctypes.data, stride, lens.ctypes.data,
+                                  hip_backend.default_threads())
+        if rc != 0:
+            return None
+        return [out[r * stride: r * stride + int(lens[r])].tobytes() for r in range(rows)]
+    return fmt
+
+
+def _csv_row_bodies(m):
+    """The float fields of every row of `m` at once (tests; the writer goes chunk by chunk)."""
+    fmt = _csv_row_formatter()
+    return None if fmt is None else fmt(np.ascontiguousarray(m))
 
 
 def write_matrix_csv_python(files, matrix, output):
@@ -225,9 +253,20 @@ def blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress=False
     todo = [(a, b) for a in range(len(groups)) for b in range(a, len(groups))][rank::max(world, 1)]
     if show_progress and rank == 0:
         todo = tqdm(todo)
-    for a, b in todo:
-        block(groups[a], groups[b] if b != a else None)
+    failure = None
+    try:
+        for a, b in todo:
+            block(groups[a], groups[b] if b != a else None)
+    except click.ClickException as e:        # (a pair that fits no upload) -- the other ranks must hear of it before the data reduce
+        if world <= 1:
+            raise
+        failure = e
     if world > 1:
+        # agree on failure first: a rank that raised alone would leave the others blocked in the reduce below
+        bad = all_reduce(np.array([1 if failure is not None else 0], dtype=np.int64))
+        if int(bad[0]):
+            raise failure if failure is not None else click.ClickException(
+                "another rank could not compute its share of the pairs (see its message); no matrix was written")
         singles, pairs = all_reduce(singles), all_reduce(pairs)
     return singles, pairs
 
@@ -283,11 +322,18 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
         from .hip_backend import HipContext
         ctx_factory = HipContext
     ctx = ctx_factory(local)
+    deflate = algorithm in DEFLATE
+    if deflate or world > 1:
+        # phase A of lz4 (single sizes + prefix snapshots) on demand: a gzip / zlib run never needs it, and a rank of a
+        # sharded run computes it for its own rows only (the sizes ride on the tile gathers)
+        ctx.set_option("defer_singles", 1)
     try:
         # every file is parsed ONCE, by host threads inside the library, then
         # uploaded; phase A (singles + prefix snapshots) runs as part of the upload
         from .hip_backend import ArenaTooBig
-        too_big = sum(os.path.getsize(f) for f in files) * 9 // 10 > _arena_limit()    # no point in parsing the whole set first
+        # File bytes are not residues (headers, line ends, white space): only a set FAR over the limit skips the attempt -- no
+        # point in parsing all of it first --, anything else is tried and the library says when it does not fit
+        too_big = sum(os.path.getsize(f) for f in files) > _arena_limit() * 3 // 2
         try:
             if not too_big:
                 ctx.upload_fasta([f.absolute() for f in files], reverse_complement=reverse_complement)
@@ -296,7 +342,7 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
         if too_big:
             if save_directory is not None:
                 raise click.ClickException("-s/--save-compression on the HIP backend needs the whole set in one upload "
-                                           "(the set exceeds the 4.29 GB of residues one upload holds)")
+                                           f"(this set does not fit the {_arena_limit() / 1e9:.2f} GB of residues one upload holds)")
             if chatty:
                 click.secho("Compressing pairs...", fg="green")
             reduce = None
@@ -306,8 +352,11 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
             singles, pairs = blocked_sizes(ctx, files, algorithm, reverse_complement, show_progress and chatty,
                                            world=world, rank=rank, all_reduce=reduce)
             return ncd_matrix(singles, pairs) if rank == 0 else None
-        deflate = algorithm in DEFLATE
-        singles = (ctx.deflate_singles(algorithm) if deflate else ctx.singles()).astype(np.int64) + GETSIZEOF_OVERHEAD
+        singles = None
+        if deflate:
+            singles = ctx.deflate_singles(algorithm)
+        elif world == 1:
+            singles = ctx.singles()
         if chatty:
             click.secho("Compressing pairs...", fg="green")
         if world > 1:
@@ -319,8 +368,7 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
             if deflate:
                 pairs = all_pairs_deflate_hip(ctx, n, algorithm, lengths=lengths)
             else:
-                pairs = all_pairs_hip(ctx, n, lengths=lengths)
-            pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
+                pairs, singles = all_pairs_hip(ctx, n, lengths=lengths, with_singles=True)
         elif deflate:
             tile = max(1, (1 << 18) // max(n, 1))
             starts = range(0, n, tile)
@@ -328,7 +376,6 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
                 starts = tqdm(starts, total=(n + tile - 1) // tile)
             pairs = (np.concatenate([ctx.deflate_pairs(algorithm, r0, min(n, r0 + tile)) for r0 in starts])
                      if n else np.zeros((0, 0), np.uint32))
-            pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
         else:
             # row tiles so that --show-progress has something to show on large inputs; results are
             # identical to one call
@@ -337,7 +384,6 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
             if show_progress and n > tile:
                 starts = tqdm(starts, total=(n + tile - 1) // tile)
             pairs = np.concatenate([ctx.pairs(r0, min(n, r0 + tile)) for r0 in starts]) if n else np.zeros((0, 0), np.uint32)
-            pairs = pairs.astype(np.int64) + GETSIZEOF_OVERHEAD
         if save_directory is not None and rank == 0:
             save_lz4_blobs(ctx, files, save_directory)
     finally:
@@ -348,7 +394,8 @@ def gpu_matrix(files, algorithm, reverse_complement, show_progress, save_directo
                 dist.destroy_process_group()
     if rank != 0:
         return None
-    return ncd_matrix(singles, pairs)
+    # raw uint32 sizes -> float64 NCD by the library's host threads (bit-equal to ncd_matrix: tests/test_host_logic.py)
+    return ncd_matrix_raw(np.asarray(singles, dtype=np.uint32), np.asarray(pairs, dtype=np.uint32).reshape(n, n))
 
 
 def threadpool_matrix(files, compression, num_threads, save_compression, reverse_complement, show_progress):

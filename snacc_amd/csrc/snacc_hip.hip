@@ -8,6 +8,7 @@
 #include "snk_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -91,7 +92,11 @@ struct snk_ctx_impl {
     uint16_t *d_lut_slot = nullptr, *d_lut_h2c = nullptr, *d_lut_h2c4 = nullptr;
     uint32_t *d_lut_hash = nullptr, *d_hashset = nullptr;      // d_hashset: 128 words (hash5) + 256 words (hash4)
     uint32_t *d_single = nullptr, *d_status = nullptr;
-    bool singles_done = false;
+    bool singles_done = false;       // snk_upload has completed: sequences resident (phase A may still be owed, see single_have)
+    bool defer_singles = false;      // option: snk_upload leaves phase A (single sizes + prefix snapshots) to the calls that need it,
+                                     // row by row -- a rank of a sharded run computes its own rows only, a gzip / zlib run none
+    std::vector<uint8_t> single_have;   // per sequence: phase A done
+    double up_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // host wall time of the last upload's stages (snk_upload_times)
 
     // scratch for pair launches (grown on demand)
     SnkJob *d_jobs = nullptr; size_t jobs_cap = 0; bool jobs_in_flight = false;
@@ -136,7 +141,7 @@ void free_sequences(snk_ctx_impl *c)
     dfree(c->d_far); c->far_bytes = 0; c->far_in_flight = false;
     dfree(c->d_bgt); c->bgt_bytes = 0; c->bgt_in_flight = false;
     c->has_exc.clear(); c->any_exc = false;
-    c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false;
+    c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false; c->single_have.clear();
     if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
     c->dfl = nullptr;
 }
@@ -245,6 +250,12 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
         uint32_t lanes = 0;
         if (fast_geometry(c, &lanes) != SNK_OK) return SNK_E_ARG;
+        if (singles && c->fast_lanes == 0) {
+            // phase A has N jobs, not N^2: spread them over every wave of the card (1024 sequences on 256 CUs: one chain per
+            // wave) instead of filling 84-chain workgroups on a few CUs -- the pass then takes one chain's serial parse
+            const uint64_t wv = (uint64_t)std::max(c->n_cus, 1) * waves;
+            lanes = std::min<uint32_t>(lanes, (uint32_t)std::max<uint64_t>(1u, (n_fast + wv - 1u) / wv));
+        }
         const uint32_t chains = lanes * waves;
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         SnkFastGrid G;
@@ -255,8 +266,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
-        const bool spec = c->fast_spec && !singles && far_waves == 0u && lanes <= 32u;       // two lanes per chain
-        const void *fk = singles ? (exc ? (const void *)snk_fastx_singles_kernel : (const void *)snk_fast_singles_kernel)
+        const bool spec = c->fast_spec && far_waves == 0u && lanes <= 32u;       // two lanes per chain
+        const void *fk = singles ? (exc ? (spec ? (const void *)snk_fastx_singles_kernel : (const void *)snk_fastx_singles_one_kernel)
+                                        : (spec ? (const void *)snk_fast_singles_kernel : (const void *)snk_fast_singles_one_kernel))
                        : exc ? (spec ? (c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_spec_cxx_kernel)
                                      : (c->fast_asm ? (const void *)snk_fastx_one_kernel : (const void *)snk_fastx_cxx_kernel))
                              : (spec ? (c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_spec_cxx_kernel)
@@ -515,6 +527,57 @@ int run_pairs(snk_ctx_impl *c, hipStream_t st, size_t n_fast, size_t n_bytes, si
     return SNK_OK;
 }
 
+// ---- phase A (ref:snacc/cli.py:108-116): single sizes + prefix snapshots of the sequences `rows` ----------------
+// Blocking (the snapshots must be complete before a pair launch on any stream starts from them).
+int run_singles(snk_ctx_impl *c, const std::vector<uint32_t> &rows)
+{
+    if (rows.empty()) return SNK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->jobs_in_flight) { HIPCHK(c, hipEventSynchronize(c->jobs_busy)); c->jobs_in_flight = false; }
+    std::vector<SnkJob> fast, bytes, gen;
+    std::vector<uint32_t> conv;
+    for (const uint32_t g : rows) {
+        const uint32_t spos = c->len[g] > SNK_BLOCK ? c->len[g] / SNK_BLOCK * SNK_BLOCK : 0u;
+        SnkJob jb; jb.xi = (int)g; jb.yi = -1; jb.out_idx = g; jb.snap = spos ? 1 : 0;
+        const bool f = !c->force_generic && c->is_packed[g] && c->len[g] > SNK_BLOCK;
+        if (f) { fast.push_back(jb); if (!c->any_exc) conv.push_back(g); }     // (the fastx kernel dumps snap_gen itself)
+        else if (c->len[g] > SNK_BLOCK && !c->bytes_legacy) bytes.push_back(jb);
+        else gen.push_back(jb);
+    }
+    const size_t nf = fast.size(), nb = bytes.size(), ng = gen.size(), nj = nf + nb + ng;
+    c->h_jobs = fast;
+    c->h_jobs.insert(c->h_jobs.end(), bytes.begin(), bytes.end());
+    c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
+    int rc = ensure_scratch(c, nj, 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), nj * sizeof(SnkJob), hipMemcpyHostToDevice, c->stream));
+    rc = launch_jobs(c, c->stream, c->d_jobs, nf, nb, ng, c->d_single, true);
+    if (rc) return rc;
+    DevTemp<uint32_t> ids;
+    if (!conv.empty()) {
+        HIPCHK(c, hipMalloc((void **)&ids.p, conv.size() * 4));
+        HIPCHK(c, hipMemcpyAsync(ids.p, conv.data(), conv.size() * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(snk_snap_convert_kernel, dim3((uint32_t)conv.size()), dim3(256), 0, c->stream,
+                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, c->d_lut_slot, ids.p, (uint32_t)conv.size());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    if (rc) return rc;
+    for (const uint32_t g : rows) c->single_have[g] = 1;
+    return SNK_OK;
+}
+
+// phase A for the sequences [r0, r1) that have not had it yet
+int ensure_singles(snk_ctx_impl *c, int r0, int r1)
+{
+    std::vector<uint32_t> rows;
+    for (int g = r0; g < r1; ++g)
+        if (!c->single_have[(size_t)g]) rows.push_back((uint32_t)g);
+    return run_singles(c, rows);
+}
+
 } // namespace
 
 struct snk_ctx : snk_ctx_impl {};
@@ -644,6 +707,8 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         c->far_stop_pct = (int)value;
     } else if (k == "fast_spec") {
         c->fast_spec = value != 0;
+    } else if (k == "defer_singles") {
+        c->defer_singles = value != 0;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
     } else if (k == "exc_limit") {
@@ -743,6 +808,15 @@ int snk_upload(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t
 
 static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const uint64_t *lens)
 {
+    const auto up_t0 = std::chrono::steady_clock::now();
+    auto up_last = up_t0;
+    auto up_lap = [&]() {                                   // host wall time since the previous lap (every stage ends with a stream sync)
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - up_last).count();
+        up_last = now;
+        return ms;
+    };
+    for (double &v : c->up_ms) v = 0.0;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->jobs_in_flight) { HIPCHK(c, hipEventSynchronize(c->jobs_busy)); c->jobs_in_flight = false; }
@@ -796,6 +870,8 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     for (size_t g = 0; g < n; ++g)
         if (lens[g]) HIPCHK(c, hipMemcpy(c->d_bytes + boff[g], seqs[g], lens[g], hipMemcpyHostToDevice));
 
+    c->up_ms[0] = up_lap();
+
     // ---- classify: exception granules -----------------------------------------------------------
     // A sequence goes to the 2-bit kernel when it is pure upper-case ACGT, or when at most exc_limit of its
     // 16-base granules per 2^20 bases hold another byte (N runs, IUPAC codes): those few places are served by the
@@ -809,12 +885,25 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     uint32_t *const d_raw = t_raw.p, *const d_cnt = t_cnt.p;
     HIPCHK(c, hipMemsetAsync(d_raw, 0, std::max<size_t>(ftot, 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, n * sizeof(uint32_t), c->stream));
-    for (size_t g = 0; g < n; ++g) {
-        if (!lens[g]) continue;
-        uint32_t grid = (uint32_t)std::min<uint64_t>(((lens[g] + 15) / 16 + 255) / 256, 1024);
-        hipLaunchKernelGGL(snk_excraw_kernel, dim3(grid), dim3(256), 0, c->stream,
-                           c->d_bytes + boff[g], (uint64_t)lens[g], d_raw + foff[g], d_cnt + g, lcase);
+    // one descriptor per sequence for the segmented ingest kernels (snk_ingest.hip.h): ONE launch per pass over all sequences
+    std::vector<SnkSeqDesc> desc(n);
+    for (size_t g = 0; g < n; ++g) { desc[g].boff = (uint32_t)boff[g]; desc[g].len = (uint32_t)lens[g]; desc[g].foff = foff[g]; desc[g].poff = 0u; }
+    DevTemp<SnkSeqDesc> t_desc;
+    HIPCHK(c, hipMalloc((void **)&t_desc.p, n * sizeof(SnkSeqDesc)));
+    HIPCHK(c, hipMemcpy(t_desc.p, desc.data(), n * sizeof(SnkSeqDesc), hipMemcpyHostToDevice));
+    DevTemp<uint32_t> t_ids;                                // id lists of the passes that cover a subset: [0, n) sequences with
+    HIPCHK(c, hipMalloc((void **)&t_ids.p, 3 * n * sizeof(uint32_t)));      // exceptions, [n, 2n) packed, [2n, 3n) hash set / slot stream
+    // grid.x for a pass whose threads handle `unit` bytes each, over sequences of at most max_len bytes
+    auto seg_grid_x = [&](uint64_t unit) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((((uint64_t)c->max_len + unit - 1) / unit + 255) / 256, 1), 4096); };
+    // launch `k` over the sequences ids[0..cnt) (ids == nullptr: all n), 65 535 rows of the grid at a time
+#define SNK_SEG_LAUNCH(kern, unit, ids_ptr, cnt, ...)                                                        \
+    for (size_t y0_ = 0; y0_ < (size_t)(cnt); y0_ += 65535u) {                                                \
+        const uint32_t ny_ = (uint32_t)std::min<size_t>(65535u, (size_t)(cnt) - y0_);                          \
+        hipLaunchKernelGGL(kern, dim3(seg_grid_x(unit), ny_), dim3(256), 0, c->stream, c->d_bytes, t_desc.p, \
+                           (const uint32_t *)(ids_ptr), (uint32_t)y0_, __VA_ARGS__);                           \
     }
+    SNK_SEG_LAUNCH(snk_excraw_seg_kernel, 16, nullptr, n, d_raw, d_cnt, lcase);
+    HIPCHK(c, hipGetLastError());
     std::vector<uint32_t> ecount(n);
     HIPCHK(c, hipMemcpyAsync(ecount.data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -832,13 +921,20 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false;
     std::vector<uint32_t> eoff(n, 0xFFFFFFFFu), runs, roff(n, 0);
     {
-        std::vector<uint32_t> raw;
+        std::vector<uint32_t> raw_all;                      // the raw granule flags of every sequence: ONE copy, when a candidate has any
+        bool want_raw = false;
         for (size_t g = 0; g < n; ++g) {
             const uint64_t allowed = 8u + (uint64_t)lens[g] * (uint64_t)c->exc_limit * 8u / 1048576u;     // granules: a first sieve
             c->is_packed[g] = lens[g] > 0 && (ecount[g] == 0 || (c->exc_limit > 0 && ecount[g] <= allowed));
+            want_raw |= c->is_packed[g] && ecount[g] != 0;
+        }
+        if (want_raw) {
+            raw_all.resize(ftot);
+            HIPCHK(c, hipMemcpy(raw_all.data(), d_raw, ftot * 4, hipMemcpyDeviceToHost));
+        }
+        for (size_t g = 0; g < n; ++g) {
             if (!c->is_packed[g] || ecount[g] == 0) continue;
-            raw.resize(fwords[g]);
-            HIPCHK(c, hipMemcpy(raw.data(), d_raw + foff[g], (size_t)fwords[g] * 4, hipMemcpyDeviceToHost));
+            const uint32_t *raw = raw_all.data() + foff[g];
             const size_t first = runs.size();
             for (size_t w = 0; w < fwords[g]; ++w) {
                 uint32_t bits = raw[w];
@@ -864,55 +960,56 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
             c->has_exc[g] = 1; c->any_exc = true; eoff[g] = foff[g];
         }
     }
+    c->up_ms[1] = up_lap();
+    std::vector<uint32_t> ids_packed, ids_exc;              // the sequences of the pack pass / of the passes over sequences with exceptions
     for (size_t g = 0; g < n; ++g)
-        if (c->is_packed[g]) { poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++; }
+        if (c->is_packed[g]) {
+            poff[g] = ptot; ptot += (((size_t)lens[g] + 3) / 4 + 63) / 64 * 64 + SNK_PAD; c->n_packed++;
+            desc[g].poff = (uint32_t)poff[g];
+            ids_packed.push_back((uint32_t)g);
+            if (c->has_exc[g]) ids_exc.push_back((uint32_t)g);
+        }
+    ptot += SNK_ARENA_SLACK;
+    if (ptot >= c->arena_limit)
+        return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the offset range of one upload", ptot);
+    HIPCHK(c, hipMemcpy(t_desc.p, desc.data(), n * sizeof(SnkSeqDesc), hipMemcpyHostToDevice));      // (now with the packed offsets; the classify pass has ended)
     HIPCHK(c, hipMalloc((void **)&c->d_exc_off, n * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_exc_off, eoff.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (c->any_exc) {
         HIPCHK(c, hipMalloc((void **)&c->d_exc_flags, ftot * 4));
         HIPCHK(c, hipMemsetAsync(c->d_exc_flags, 0, ftot * 4, c->stream));
-        for (size_t g = 0; g < n; ++g)
-            if (c->has_exc[g])
-                hipLaunchKernelGGL(snk_excdilate_kernel, dim3((fwords[g] + 255) / 256), dim3(256), 0, c->stream,
-                                   d_raw + foff[g], fwords[g], c->d_exc_flags + foff[g]);
+        HIPCHK(c, hipMemcpy(t_ids.p, ids_exc.data(), ids_exc.size() * 4, hipMemcpyHostToDevice));
+        SNK_SEG_LAUNCH(snk_excdilate_seg_kernel, 16 * 32, t_ids.p, ids_exc.size(), (const uint32_t *)d_raw, c->d_exc_flags);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMalloc((void **)&c->d_exc_runs, runs.size() * 4));
         HIPCHK(c, hipMemcpy(c->d_exc_runs, runs.data(), runs.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc((void **)&c->d_exc_roff, n * 4));
         HIPCHK(c, hipMemcpy(c->d_exc_roff, roff.data(), n * 4, hipMemcpyHostToDevice));
     }
-    t_raw.release();
-    ptot += SNK_ARENA_SLACK;
-    if (ptot >= c->arena_limit)
-        return fail(c, SNK_E_TOOBIG, "2-bit arena of %zu bytes exceeds the offset range of one upload", ptot);
     HIPCHK(c, hipMalloc((void **)&c->d_packed, ptot));
     HIPCHK(c, hipMemsetAsync(c->d_packed, 0, ptot, c->stream));
-    for (size_t g = 0; g < n; ++g) {
-        if (!c->is_packed[g]) continue;
-        uint64_t nb = ((uint64_t)lens[g] + 3) / 4;
-        uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 2048);
-        hipLaunchKernelGGL(snk_pack_kernel, dim3(grid), dim3(256), 0, c->stream,
-                           c->d_bytes + boff[g], (uint64_t)lens[g], c->d_packed + poff[g]);
-    }
-    if (c->any_exc) {                 // the mask arena: where the bytes of the 2-bit sequences are not ACGT
+    if (c->any_exc) {                 // the class arena: where the bytes of the 2-bit sequences are not the set's four letters
         HIPCHK(c, hipMalloc((void **)&c->d_pmask, ptot));
         HIPCHK(c, hipMemsetAsync(c->d_pmask, 0, ptot, c->stream));
-        for (size_t g = 0; g < n; ++g) {
-            if (!c->is_packed[g] || !c->has_exc[g]) continue;
-            uint64_t nb = ((uint64_t)lens[g] + 3) / 4;
-            uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 2048);
-            hipLaunchKernelGGL(snk_packmask_kernel, dim3(grid), dim3(256), 0, c->stream,
-                               c->d_bytes + boff[g], (uint64_t)lens[g], c->d_pmask + poff[g], lcase);
-        }
+        SNK_SEG_LAUNCH(snk_packmask_seg_kernel, 16, t_ids.p, ids_exc.size(), c->d_pmask, lcase);
+        HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipGetLastError());
+    if (!ids_packed.empty()) {
+        const bool all = ids_packed.size() == n;             // every sequence packed: no list
+        if (!all) HIPCHK(c, hipMemcpy(t_ids.p + n, ids_packed.data(), ids_packed.size() * 4, hipMemcpyHostToDevice));
+        SNK_SEG_LAUNCH(snk_pack_seg_kernel, 16, all ? nullptr : t_ids.p + n, ids_packed.size(), c->d_packed);
+        HIPCHK(c, hipGetLastError());
+    }
+
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->up_ms[2] = up_lap();
 
     // ---- resident hash set: can the byte kernel use the compact table? --------------------------
     c->compact_ok = false; c->n_hashes = 0; c->compact_cap = 0;
     if (c->bytes_compact_opt != 0 && !c->bytes_legacy) {
         HIPCHK(c, hipMemsetAsync(c->d_hashset, 0, 128 * sizeof(uint32_t), c->stream));
         bool any_packed = false, any_bytes = false;
+        std::vector<uint32_t> ids_h;
         for (size_t g = 0; g < n; ++g) {
             if (c->is_packed[g] && !c->force_generic) {
                 any_packed = true;                                   // contributes the 894 ACGT hashes
@@ -920,9 +1017,11 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
             }
             if (lens[g] < 5) continue;
             any_bytes = true;
-            uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 1024);
-            hipLaunchKernelGGL(snk_hashset_kernel, dim3(grid), dim3(256), 0, c->stream,
-                               c->d_bytes + boff[g], (uint64_t)lens[g], c->d_hashset);
+            ids_h.push_back((uint32_t)g);
+        }
+        if (!ids_h.empty()) {
+            HIPCHK(c, hipMemcpy(t_ids.p + 2 * n, ids_h.data(), ids_h.size() * 4, hipMemcpyHostToDevice));
+            SNK_SEG_LAUNCH(snk_hashset_seg_kernel, 1, t_ids.p + 2 * n, ids_h.size(), c->d_hashset);
         }
         HIPCHK(c, hipGetLastError());
         if (any_bytes || c->force_generic) {
@@ -953,12 +1052,20 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
         uint32_t *d_set4 = c->d_hashset + 128;
         HIPCHK(c, hipMemsetAsync(d_set4, 0, 256 * sizeof(uint32_t), c->stream));
         bool any = false;
+        std::vector<uint32_t> ids_h;
         for (size_t g = 0; g < n; ++g) {
             if (lens[g] > SNK_BLOCK || lens[g] < 4) continue;
             any = true;
-            uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 256);
-            hipLaunchKernelGGL(snk_hashset4_kernel, dim3(grid), dim3(256), 0, c->stream,
-                               c->d_bytes + boff[g], (uint64_t)lens[g], d_set4);
+            ids_h.push_back((uint32_t)g);
+        }
+        if (any) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));              // (the list's third part may still be read by the pass above)
+            HIPCHK(c, hipMemcpy(t_ids.p + 2 * n, ids_h.data(), ids_h.size() * 4, hipMemcpyHostToDevice));
+            for (size_t y0 = 0; y0 < ids_h.size(); y0 += 65535u) {   // (sequences of <= 64 KiB: 256 blocks of 256 cover the longest)
+                const uint32_t ny = (uint32_t)std::min<size_t>(65535u, ids_h.size() - y0);
+                hipLaunchKernelGGL(snk_hashset4_seg_kernel, dim3(64, ny), dim3(256), 0, c->stream, c->d_bytes, t_desc.p,
+                                   (const uint32_t *)(t_ids.p + 2 * n), (uint32_t)y0, d_set4);
+            }
         }
         HIPCHK(c, hipGetLastError());
         if (any) {
@@ -985,15 +1092,14 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
         if (need && !c->bytes_legacy && c->max_len > 0 && (uint64_t)c->max_len * 2u > SNK_BLOCK) {
             HIPCHK(c, hipMalloc((void **)&c->d_slots, btot * sizeof(uint16_t)));
             HIPCHK(c, hipMemsetAsync(c->d_slots, 0, btot * sizeof(uint16_t), c->stream));
-            for (size_t g = 0; g < n; ++g) {
-                if (lens[g] < 5) continue;
-                uint32_t grid = (uint32_t)std::min<uint64_t>((lens[g] + 255) / 256, 2048);
-                hipLaunchKernelGGL(snk_slotstream_kernel, dim3(grid), dim3(256), 0, c->stream, c->d_bytes + boff[g], (uint64_t)lens[g],
-                                   c->compact_ok ? (const uint16_t *)c->d_lut_h2c : (const uint16_t *)nullptr, c->d_slots + boff[g]);
-            }
+            SNK_SEG_LAUNCH(snk_slotstream_seg_kernel, 1, nullptr, n,
+                           c->compact_ok ? (const uint16_t *)c->d_lut_h2c : (const uint16_t *)nullptr, c->d_slots);
             HIPCHK(c, hipGetLastError());
         }
     }
+#undef SNK_SEG_LAUNCH
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->up_ms[3] = up_lap();
 
     // ---- per-sequence tables ------------------------------------------------------------------
     std::vector<const uint8_t *> bp(n); std::vector<uint32_t> pp(n), bo(n);
@@ -1028,49 +1134,43 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     HIPCHK(c, hipMemsetAsync(c->d_snap_out, 0, n * 4, c->stream));
     c->n = n_seq;
 
-    // ---- singles + snapshots (phase A) --------------------------------------------------------
-    std::vector<SnkJob> fast, bytes, gen;
-    std::vector<uint32_t> conv;
-    for (size_t g = 0; g < n; ++g) {
-        SnkJob jb; jb.xi = (int)g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
-        const bool f = !c->force_generic && c->is_packed[g] && lens[g] > SNK_BLOCK;
-        if (f) { fast.push_back(jb); if (!c->any_exc) conv.push_back((uint32_t)g); }     // (the fastx kernel dumps snap_gen itself)
-        else if (lens[g] > SNK_BLOCK && !c->bytes_legacy) bytes.push_back(jb);
-        else gen.push_back(jb);
-    }
-    const size_t nf = fast.size(), nb = bytes.size(), ng = gen.size();
-    c->h_jobs = fast;
-    c->h_jobs.insert(c->h_jobs.end(), bytes.begin(), bytes.end());
-    c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
-    int rc = ensure_scratch(c, n, 0);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), n * sizeof(SnkJob), hipMemcpyHostToDevice, c->stream));
-    rc = launch_jobs(c, c->stream, c->d_jobs, nf, nb, ng, c->d_single, true);
-    if (rc) return rc;
-    if (!conv.empty()) {
-        DevTemp<uint32_t> ids;
-        HIPCHK(c, hipMalloc((void **)&ids.p, conv.size() * 4));
-        HIPCHK(c, hipMemcpyAsync(ids.p, conv.data(), conv.size() * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(snk_snap_convert_kernel, dim3((uint32_t)conv.size()), dim3(256), 0, c->stream,
-                           c->d_snap_fast, c->d_snap_gen, c->d_lut_hash, c->d_lut_slot, ids.p, (uint32_t)conv.size());
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    rc = check_status(c);
-    if (rc) return rc;
+    c->single_have.assign(n, 0);
     c->singles_done = true;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->up_ms[4] = up_lap();
+    if (!c->defer_singles) {
+        const int rc = ensure_singles(c, 0, n_seq);        // phase A for every sequence, as part of the upload
+        if (rc) return rc;
+    }
+    c->up_ms[5] = up_lap();
+    c->up_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - up_t0).count();
+    return SNK_OK;
+}
+
+int snk_singles_rows(snk_ctx *c, int r0, int r1, uint32_t *sizes)
+{
+    if (!c) return SNK_E_ARG;
+    if (r0 < 0 || r1 < r0 || r1 > c->n || (!sizes && r1 > r0)) return fail(c, SNK_E_ARG, "bad row range [%d,%d)", r0, r1);
+    if (!c->singles_done && c->n) return fail(c, SNK_E_STATE, "snk_upload has not completed");
+    if (r1 == r0) return SNK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = ensure_singles(c, r0, r1);              // (option defer_singles: phase A of these rows runs now)
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(sizes, c->d_single + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost));
     return SNK_OK;
 }
 
 int snk_singles(snk_ctx *c, uint32_t *sizes)
 {
     if (!c || (!sizes && c->n)) return fail(c, SNK_E_ARG, "bad arguments");
-    if (!c->singles_done && c->n) return fail(c, SNK_E_STATE, "snk_upload has not completed");
-    if (!c->n) return SNK_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(sizes, c->d_single, (size_t)c->n * 4, hipMemcpyDeviceToHost));
-    return SNK_OK;
+    return snk_singles_rows(c, 0, c->n, sizes);
+}
+
+int snk_upload_times(const snk_ctx *c, double *ms, int cap)
+{
+    if (!c || cap < 0 || (cap && !ms)) return SNK_E_ARG;
+    for (int k = 0; k < cap && k < 7; ++k) ms[k] = c->up_ms[k];
+    return 7;
 }
 
 int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream)
@@ -1085,7 +1185,8 @@ int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream
     if ((uint64_t)np > 0xFFF00000ull)          // job numbers and output indices are 32-bit on the device (and the job counter overshoots a little)
         return fail(c, SNK_E_TOOBIG, "%zu ordered pairs in one launch (rows [%d,%d) x %zu): at most 0xFFF00000; tile the rows", np, r0, r1, N);
     size_t nf = 0, nb = 0, ng = 0;
-    int rc = SNK_OK;
+    int rc = ensure_singles(c, r0, r1);        // the prefix snapshots of these rows (a no-op unless phase A was deferred)
+    if (rc) return rc;
     if (!c->force_generic && c->n_packed == c->n && (uint64_t)c->min_len * 2u > SNK_BLOCK && (uint64_t)c->max_len * 2u < 0x7E000000ull) {
         nf = np; c->dense_tile = true;             // every pair fits the 2-bit kernel: no job list at all
     } else {
@@ -1155,6 +1256,17 @@ int snk_pairs_list(snk_ctx *c, int n_pairs, const int32_t *ij, uint32_t *sizes)
     if (!n_pairs) return SNK_OK;
     HIPCHK(c, hipSetDevice(c->device));
     size_t nf = 0, nb = 0, ng = 0;
+    {   // the prefix snapshots the list needs (a no-op unless phase A was deferred)
+        std::vector<uint32_t> rows;
+        std::vector<uint8_t> seen((size_t)c->n, 0);
+        for (int t = 0; t < n_pairs; ++t) {
+            const int i = ij[2 * t];
+            if (i < 0 || i >= c->n) return fail(c, SNK_E_ARG, "pair index out of range");
+            if (!seen[(size_t)i] && !c->single_have[(size_t)i]) { seen[(size_t)i] = 1; rows.push_back((uint32_t)i); }
+        }
+        const int rc0 = run_singles(c, rows);
+        if (rc0) return rc0;
+    }
     // sort by suffix for locality, keep the caller's output order
     std::vector<uint32_t> order((size_t)n_pairs);
     for (uint32_t t = 0; t < (uint32_t)n_pairs; ++t) order[t] = t;

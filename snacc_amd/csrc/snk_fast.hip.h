@@ -2011,9 +2011,17 @@ __global__ void __launch_bounds__(512) snk_fast_spec_cxx_kernel(SnkTables T, Snk
     snk_fast_wave<false, false, false, true>(T, G, lanes, out, status);
 }
 
-// phase A: single sequences + prefix snapshots at upload (same code, own symbol so that profiles
-// keep the two phases apart)
+// phase A: single sequences + prefix snapshots at upload (same code, own symbols so that profiles keep the two phases
+// apart): two lanes per chain as in phase B (x-only blocks are what the DUAL form of the loop serves), one lane (fast_spec = 0)
 __global__ void __launch_bounds__(512) snk_fast_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    snk_fast_wave<true, false, false, true>(T, G, lanes, out, status);
+}
+__global__ void __launch_bounds__(512) snk_fast_singles_one_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, false>(T, G, lanes, out, status);
 }
@@ -2046,6 +2054,10 @@ __global__ void __launch_bounds__(512) snk_fastx_cxx_kernel(SnkTables T, SnkFast
     snk_fast_kernel_body<false, true>(T, G, lanes, out, status);
 }
 __global__ void __launch_bounds__(512) snk_fastx_singles_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    snk_fastx_spec_body<true>(T, G, lanes, out, status);
+}
+__global__ void __launch_bounds__(512) snk_fastx_singles_one_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     snk_fast_kernel_body<true, true>(T, G, lanes, out, status);
 }

@@ -12,6 +12,7 @@
 // Byte-level caveat: right-stripping knows ASCII white space and 0x1c-0x1f, not Unicode spaces.
 #include "snacc_hip.h"
 
+#include <algorithm>
 #include <atomic>
 #include <charconv>
 #include <cmath>
@@ -264,6 +265,44 @@ int snk_csv_rows_f64(const double *m, uint64_t rows, uint64_t cols, char *out, u
     const int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
     std::vector<std::thread> ts;
     for (int t = 1; t < nt; ++t) ts.emplace_back(work);
+    work();
+    for (auto &t : ts) t.join();
+    return SNK_OK;
+}
+
+// NCD matrix from integer sizes (ref:snacc/cli.py:131-136 + ref:snacc/pairwise_ncd.py:93-111):
+//   out[i][j] = (min(P[i][j], P[j][i]) - min(S[i], S[j])) / max(S[i], S[j]),  S = singles + overhead, P = pairs + overhead,
+// int64 arithmetic, then ONE float64 division -- the same two correctly rounded operations as the reference's Python
+// (int - int, int / int with both below 2^53) and as snacc_amd.matrix.ncd_matrix, which the CPU tests hold it equal to.
+// Tiles of 64 x 64 keep the transposed reads in cache; host threads take tile rows.
+int snk_ncd_matrix_u32(const uint32_t *singles, const uint32_t *pairs, uint64_t n, uint32_t overhead, double *out, int n_threads)
+{
+    if (n && (!singles || !pairs || !out)) return SNK_E_ARG;
+    const uint64_t TB = 64;
+    const uint64_t tiles = (n + TB - 1) / TB;
+    std::atomic<uint64_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const uint64_t ti = next.fetch_add(1);
+            if (ti >= tiles) return;
+            const uint64_t i0 = ti * TB, i1 = std::min(n, i0 + TB);
+            for (uint64_t j0 = 0; j0 < n; j0 += TB) {
+                const uint64_t j1 = std::min(n, j0 + TB);
+                for (uint64_t i = i0; i < i1; ++i) {
+                    const int64_t si = (int64_t)singles[i] + overhead;
+                    for (uint64_t j = j0; j < j1; ++j) {
+                        const int64_t sj = (int64_t)singles[j] + overhead;
+                        const int64_t pij = (int64_t)pairs[i * n + j] + overhead, pji = (int64_t)pairs[j * n + i] + overhead;
+                        const int64_t num = std::min(pij, pji) - std::min(si, sj);
+                        out[i * n + j] = (double)num / (double)std::max(si, sj);
+                    }
+                }
+            }
+        }
+    };
+    const int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    std::vector<std::thread> ts;
+    for (int t = 1; t < nt && (uint64_t)t < tiles; ++t) ts.emplace_back(work);
     work();
     for (auto &t : ts) t.join();
     return SNK_OK;

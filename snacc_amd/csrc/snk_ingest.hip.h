@@ -172,3 +172,169 @@ __global__ void snk_snap_convert_kernel(const uint32_t *snap_fast, uint32_t *sna
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) dst[lut_hash[k]] = src[lut_slot[k]];
 }
+
+// =========================================================================
+//  segmented forms: ONE launch over many sequences (round 4)
+// =========================================================================
+// The per-sequence kernels above cost one launch per sequence and pass -- ~5 000 launches and copies for 1024 genomes,
+// a fifth of the upload's wall time.  Here blockIdx.y names the sequence (entry y0 + blockIdx.y of the launch's id list,
+// or the sequence of that number when ids == NULL) and the blocks of a row stride over it; every thread handles one
+// 16-base granule with one 16-byte load (sequences start 64-byte aligned in the ASCII arena, which is zero behind their ends).
+struct SnkSeqDesc {
+    uint32_t boff;      // byte offset in the ASCII arena
+    uint32_t len;
+    uint32_t foff;      // first word of the sequence's granule flags
+    uint32_t poff;      // byte offset in the packed / class arena (packed sequences only)
+};
+
+__device__ __forceinline__ uint32_t snk_seg_id(const uint32_t *ids, uint32_t y0)
+{
+    const uint32_t k = y0 + blockIdx.y;
+    return ids ? ids[k] : k;
+}
+
+// 4 ASCII letters -> their four 2-bit codes ((c >> 1) & 3) in one byte, first letter lowest
+__device__ __forceinline__ uint32_t snk_pack4(uint32_t w)
+{
+    const uint32_t t = (w >> 1) & 0x03030303u;
+    return (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+}
+
+// 4 bytes -> their four 2-bit classes (00 a letter of the set's case, 01 of the other case, 11 another byte)
+__device__ __forceinline__ uint32_t snk_class4(uint32_t w, uint32_t lcase)
+{
+    uint32_t v = 0u;
+    for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t c = (w >> (8u * b)) & 255u, u = c & ~0x20u;
+        const bool letter = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+        if (!letter) v |= 3u << (2u * b);
+        else if ((c & 0x20u) != lcase) v |= 1u << (2u * b);
+    }
+    return v;
+}
+
+// snk_excraw_kernel for many sequences: raw[foff + g / 32] bit g % 32 = granule g holds a byte that is not one of the
+// set's four letters; count[sequence] += flagged granules.
+__global__ void snk_excraw_seg_kernel(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0,
+                                      uint32_t *raw, uint32_t *count, uint32_t lcase)
+{
+    const uint32_t s = snk_seg_id(ids, y0);
+    const SnkSeqDesc d = desc[s];
+    const uint32_t ngran = (d.len + 15u) >> 4;
+    const uint4 *src = (const uint4 *)(arena + d.boff);
+    const uint32_t la = 'A' | lcase, lc = 'C' | lcase, lg = 'G' | lcase, lt = 'T' | lcase;
+    uint32_t mine = 0u;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngran; g += gridDim.x * blockDim.x) {
+        const uint4 v = src[g];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        const uint32_t left = d.len - 16u * g, nv = left < 16u ? left : 16u;
+        bool bad = false;
+        for (uint32_t b = 0; b < 16u; ++b) {
+            const uint32_t c = (w[b >> 2] >> (8u * (b & 3u))) & 255u;
+            bad |= (b < nv) & !((c == la) | (c == lc) | (c == lg) | (c == lt));
+        }
+        if (bad) { atomicOr(&raw[d.foff + (g >> 5)], 1u << (g & 31u)); mine++; }
+    }
+    if (mine) atomicAdd(&count[s], mine);
+}
+
+// snk_excdilate_kernel for many sequences (fwords = words of the sequence's flags: ((len + 15) / 16 + 31) / 32 + 2)
+__global__ void snk_excdilate_seg_kernel(const uint8_t * /* arena: unused */, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0,
+                                         const uint32_t *raw, uint32_t *out)
+{
+    const uint32_t s = snk_seg_id(ids, y0);
+    const SnkSeqDesc d = desc[s];
+    const uint32_t nwords = (((d.len + 15u) >> 4) + 31u) / 32u + 2u;
+    const uint32_t *r = raw + d.foff;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+        const uint32_t v = r[w];
+        const uint32_t lo = w ? r[w - 1u] >> 31 : 0u, hi = w + 1u < nwords ? r[w + 1u] << 31 : 0u;
+        out[d.foff + w] = v | (v << 1) | (v >> 1) | lo | hi;
+    }
+}
+
+// snk_pack_kernel / snk_packmask_kernel for many sequences: 16 bases -> one 32-bit word of the packed (MASK: class) arena
+template <bool MASK>
+__device__ __forceinline__ void snk_pack_seg_body(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0,
+                                                  uint8_t *packed, uint32_t lcase)
+{
+    const uint32_t s = snk_seg_id(ids, y0);
+    const SnkSeqDesc d = desc[s];
+    const uint32_t ngran = (d.len + 15u) >> 4;
+    const uint4 *src = (const uint4 *)(arena + d.boff);
+    uint32_t *dst = (uint32_t *)(packed + d.poff);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngran; g += gridDim.x * blockDim.x) {
+        uint4 v = src[g];
+        if (MASK) {
+            // (behind the end the arena holds zero bytes: class 00 there, as the per-sequence kernel writes it)
+            const uint32_t left = d.len - 16u * g;
+            uint32_t w[4] = { v.x, v.y, v.z, v.w };
+            if (left < 16u)
+                for (uint32_t b = left; b < 16u; ++b) w[b >> 2] = (w[b >> 2] & ~(255u << (8u * (b & 3u)))) | ((uint32_t)('A' | lcase) << (8u * (b & 3u)));
+            dst[g] = snk_class4(w[0], lcase) | (snk_class4(w[1], lcase) << 8) | (snk_class4(w[2], lcase) << 16) | (snk_class4(w[3], lcase) << 24);
+        } else {
+            dst[g] = snk_pack4(v.x) | (snk_pack4(v.y) << 8) | (snk_pack4(v.z) << 16) | (snk_pack4(v.w) << 24);
+        }
+    }
+}
+__global__ void snk_pack_seg_kernel(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0, uint8_t *packed)
+{
+    snk_pack_seg_body<false>(arena, desc, ids, y0, packed, 0u);
+}
+__global__ void snk_packmask_seg_kernel(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0, uint8_t *mask, uint32_t lcase)
+{
+    snk_pack_seg_body<true>(arena, desc, ids, y0, mask, lcase);
+}
+
+// snk_hashset_kernel / snk_hashset4_kernel for many sequences (H4: the one-shot hash of 4 bytes, 256 words; else 128)
+template <bool H4>
+__device__ __forceinline__ void snk_hashset_seg_body(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0, uint32_t *set)
+{
+    constexpr uint32_t W = H4 ? 256u : 128u, K = H4 ? 4u : 5u;
+    __shared__ uint32_t local[W];
+    for (uint32_t t = threadIdx.x; t < W; t += blockDim.x) local[t] = 0u;
+    __syncthreads();
+    const uint32_t s = snk_seg_id(ids, y0);
+    const SnkSeqDesc d = desc[s];
+    const uint8_t *bytes = arena + d.boff;
+    if (d.len >= K) {
+        const uint32_t last = d.len - K;
+        for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p <= last; p += gridDim.x * blockDim.x) {
+            uint64_t v = 0;
+            for (uint32_t b = 0; b < K; ++b) v |= (uint64_t)bytes[p + b] << (8u * b);
+            const uint32_t h = H4 ? snk_hash4(v) : snk_hash5(v);
+            atomicOr(&local[h >> 5], 1u << (h & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < W; t += blockDim.x)
+        if (local[t]) atomicOr(&set[t], local[t]);
+}
+__global__ void snk_hashset_seg_kernel(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0, uint32_t *set)
+{
+    snk_hashset_seg_body<false>(arena, desc, ids, y0, set);
+}
+__global__ void snk_hashset4_seg_kernel(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0, uint32_t *set)
+{
+    snk_hashset_seg_body<true>(arena, desc, ids, y0, set);
+}
+
+// snk_slotstream_kernel for many sequences (slots: the stream of the whole ASCII arena, same offsets)
+__global__ void snk_slotstream_seg_kernel(const uint8_t *arena, const SnkSeqDesc *desc, const uint32_t *ids, uint32_t y0,
+                                          const uint16_t *lut /* NULL: slot = hash */, uint16_t *slots)
+{
+    const uint32_t s = snk_seg_id(ids, y0);
+    const SnkSeqDesc d = desc[s];
+    const uint8_t *bytes = arena + d.boff;
+    uint16_t *out = slots + d.boff;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < d.len; p += gridDim.x * blockDim.x) {
+        uint32_t v = 0u;
+        if (p + 5u <= d.len) {
+            uint64_t w = 0;
+            for (uint32_t b = 0; b < 5u; ++b) w |= (uint64_t)bytes[p + b] << (8u * b);
+            const uint32_t h = snk_hash5(w);
+            v = lut ? lut[h] : h;
+        }
+        out[p] = (uint16_t)v;
+    }
+}

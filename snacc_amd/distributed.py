@@ -130,13 +130,19 @@ def allgather_check(gathered, tile, rank, world, group=None):
     return ok
 
 
-def all_pairs_sharded(n, rows_fn, group=None, device=None, weights=None, tile_rows=None):
+def all_pairs_sharded(n, rows_fn, group=None, device=None, weights=None, tile_rows=None, singles_fn=None):
     """Assemble the full (n, n) uint32 size matrix on every rank.
 
     rows_fn(r0, r1) -> either a numpy uint32 array of shape (r1-r0, n) or a torch int32/uint32 tensor
     already on `device` (the HIP backend writes straight into such a tensor).  `weights`: per-row work
     (:func:`shard_rows_weighted`); None = equal row counts.  `tile_rows`: rows per launch/gather; the
     gather of one tile is asynchronous and overlaps the next tile's rows_fn.
+
+    `singles_fn(r0, r1)` -> numpy uint32 single sizes of the sequences [r0, r1): called ONCE, for the rank's
+    own block of rows, before its tiles (on the HIP backend this is where phase A of those rows -- and of
+    no others -- runs: SURVEY.md 8e, "computed once on the owning GPU").  The sizes ride on the tile gathers:
+    every tile carries ceil(tile_rows / n) extra rows that hold the single sizes of its rows.  Returns
+    (full, singles) then, with `singles` the (n,) uint32 array assembled from every rank's share.
     """
     import torch
     import torch.distributed as dist
@@ -151,6 +157,10 @@ def all_pairs_sharded(n, rows_fn, group=None, device=None, weights=None, tile_ro
     per = max([b - a for a, b in blocks] + [0])          # every rank gathers `per` rows (padded)
     tile_rows = max(1, min(per, tile_rows or per))
     n_tiles = (per + tile_rows - 1) // tile_rows if per else 0
+    extra = (tile_rows + n - 1) // n if (singles_fn is not None and n) else 0      # rows that carry the tile's single sizes
+    own_singles = None
+    if singles_fn is not None:
+        own_singles = np.ascontiguousarray(singles_fn(r0, r1), dtype=np.uint32) if r1 > r0 else np.zeros(0, np.uint32)
     gathered, works, tiles = [], [], []          # tiles: kept alive until their gathers have completed
     for k in range(n_tiles):
         t0 = min(r0 + k * tile_rows, r1)
@@ -161,9 +171,12 @@ def all_pairs_sharded(n, rows_fn, group=None, device=None, weights=None, tile_ro
             if device is not None:
                 mine = mine.to(device)
         dev = mine.device if mine is not None else (device if device is not None else torch.device("cpu"))
-        tile = torch.zeros((tile_rows, n), dtype=torch.int32, device=dev)
+        tile = torch.zeros((tile_rows + extra, n), dtype=torch.int32, device=dev)
         if mine is not None:
             tile[: t1 - t0] = mine.reshape(t1 - t0, n)
+            if extra:
+                sv = torch.from_numpy(own_singles[t0 - r0: t1 - r0].view(np.int32))
+                tile.view(-1)[tile_rows * n: tile_rows * n + (t1 - t0)] = sv.to(dev)
         tiles.append(tile)
         g, work = gather_tile(tile, world, group=group, async_op=world > 1)
         gathered.append(g)
@@ -175,14 +188,17 @@ def all_pairs_sharded(n, rows_fn, group=None, device=None, weights=None, tile_ro
             except Exception as e:  # noqa: BLE001
                 _die("all_gather (wait)", e)
     full = np.zeros((n, n), dtype=np.uint32)
+    singles = np.zeros(n, dtype=np.uint32)
     for k, g in enumerate(gathered):
-        g = g.cpu().numpy().view(np.uint32).reshape(world, tile_rows, n)
+        g = g.cpu().numpy().view(np.uint32).reshape(world, tile_rows + extra, n)
         for r, (a, b) in enumerate(blocks):
             t0 = min(a + k * tile_rows, b)
             t1 = min(t0 + tile_rows, b)
             if t1 > t0:
                 full[t0:t1] = g[r, : t1 - t0]
-    return full
+                if extra:
+                    singles[t0:t1] = g[r, tile_rows:].reshape(-1)[: t1 - t0]
+    return (full, singles) if singles_fn is not None else full
 
 
 def _torch_device(ctx):
@@ -190,10 +206,12 @@ def _torch_device(ctx):
     return getattr(ctx, "torch_device", None) or torch.device("cuda", ctx.device)
 
 
-def all_pairs_hip(ctx, n, group=None, lengths=None):
+def all_pairs_hip(ctx, n, group=None, lengths=None, with_singles=False):
     """Sharded phase B on the HIP backend: each rank launches its row tiles on the context's own stream,
     writing into a device tensor; each finished tile is all-gathered (backend "nccl" = RCCL) while the
-    next one runs."""
+    next one runs.  `with_singles`: phase A too -- every rank computes the single sizes (and prefix snapshots)
+    of ITS rows only (`ctx.singles_rows`; the context was created with ``defer_singles=1``) and the sizes ride on
+    the tile gathers; returns (pairs, singles)."""
     import torch
 
     dev = _torch_device(ctx)
@@ -208,7 +226,8 @@ def all_pairs_hip(ctx, n, group=None, lengths=None):
 
     weights = lz4_row_weights(lengths) if lengths is not None else None
     tile = max(1, (4 << 20) // max(n, 1))
-    return all_pairs_sharded(n, rows_fn, group=group, device=dev, weights=weights, tile_rows=tile)
+    return all_pairs_sharded(n, rows_fn, group=group, device=dev, weights=weights, tile_rows=tile,
+                             singles_fn=ctx.singles_rows if with_singles else None)
 
 
 def all_pairs_deflate_hip(ctx, n, algorithm, group=None, lengths=None):

@@ -21,6 +21,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "snk_version", "snk_last_error", "snk_ctx_create", "snk_ctx_destroy", "snk_set_option",
     "snk_upload", "snk_num_sequences", "snk_lengths", "snk_num_packed", "snk_fast_chains", "snk_num_compact_hashes", "snk_singles", "snk_pairs",
+    "snk_singles_rows", "snk_upload_times", "snk_ncd_matrix_u32",
     "snk_pairs_device", "snk_pairs_list", "snk_frames_list", "snk_sync", "snk_last_pairs_ms", "snk_pairs_ms_log",
     "snk_fasta_extract", "snk_fasta_extract_many", "snk_fasta_last_error", "snk_free", "snk_upload_fasta", "snk_csv_rows_f64",
     "snk_deflate_prepare", "snk_deflate_singles", "snk_deflate_pairs", "snk_deflate_pairs_list", "snk_deflate_pairs_device", "snk_deflate_last_ms",
@@ -102,6 +103,12 @@ def load():
     L.snk_num_compact_hashes.argtypes = [vp]
     L.snk_singles.restype = i32
     L.snk_singles.argtypes = [vp, u32p]
+    L.snk_singles_rows.restype = i32
+    L.snk_singles_rows.argtypes = [vp, i32, i32, u32p]
+    L.snk_upload_times.restype = i32
+    L.snk_upload_times.argtypes = [vp, vp, i32]
+    L.snk_ncd_matrix_u32.restype = i32
+    L.snk_ncd_matrix_u32.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, vp, i32]
     L.snk_pairs.restype = i32
     L.snk_pairs.argtypes = [vp, i32, i32, u32p]
     L.snk_pairs_device.restype = i32
@@ -286,6 +293,19 @@ class HipContext:
         out = np.zeros(self.n, dtype=np.uint32)
         self._check(self._L.snk_singles(self._h, out.ctypes.data), "snk_singles")
         return out
+
+    def singles_rows(self, row_begin, row_end):
+        """Single sizes of the sequences [row_begin, row_end) (with ``defer_singles``: their phase A runs now)."""
+        out = np.zeros(max(row_end - row_begin, 0), dtype=np.uint32)
+        self._check(self._L.snk_singles_rows(self._h, row_begin, row_end, out.ctypes.data), "snk_singles_rows")
+        return out
+
+    def upload_times(self):
+        """Host wall time (s) of the last upload's stages (``snk_upload_times``)."""
+        buf = (ctypes.c_double * 7)()
+        self._L.snk_upload_times(self._h, buf, 7)
+        keys = ("h2d", "classify", "pack", "hashsets_slotstream", "tables", "singles", "total")
+        return {k: buf[i] * 1e-3 for i, k in enumerate(keys)}
 
     def pairs(self, row_begin=0, row_end=None):
         row_end = self.n if row_end is None else row_end

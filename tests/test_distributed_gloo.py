@@ -45,8 +45,20 @@ def _worker_sharded(rank, world, port, n, length, outdir, weighted, tile_rows):
         calls.append((r0, r1))
         return pairs_mt(seqs, r0, r1, 2)
 
+    asked = []
+
+    def singles_fn(r0, r1):                    # phase A of the rank's OWN rows only; the sizes ride on the tile gathers
+        import oracle
+        asked.append((r0, r1))
+        return np.array([oracle.lz4f_size(s) for s in seqs[r0:r1]], dtype=np.uint32)
+
     weights = lz4_row_weights([len(s) for s in seqs]) if weighted else None
     full = all_pairs_sharded(n, rows_fn, weights=weights, tile_rows=tile_rows)
+    full2, singles = all_pairs_sharded(n, rows_fn, weights=weights, tile_rows=tile_rows, singles_fn=singles_fn)
+    assert np.array_equal(full, full2)
+    calls[:] = calls[: len(calls) // 2]
+    np.save(os.path.join(outdir, f"singles_{rank}.npy"), singles)
+    np.save(os.path.join(outdir, f"asked_{rank}.npy"), np.array(asked, dtype=np.int64).reshape(-1, 2))
     np.save(os.path.join(outdir, f"full_{rank}.npy"), full)
     np.save(os.path.join(outdir, f"rows_{rank}.npy"), np.array(calls, dtype=np.int64).reshape(-1, 2))
     # bench.py's step: one tile per rank, gathered, checked on every rank
@@ -74,8 +86,14 @@ def test_allgather_assembly_matches_single_process(tmp_path, world, n, weighted,
     blocks = (shard_rows_weighted(lz4_row_weights([len(s) for s in seqs]), world) if weighted
               else [shard_rows(n, world, r)[:2] for r in range(world)])
     covered = []
+    import oracle
+    want_singles = np.array([oracle.lz4f_size(s) for s in seqs], dtype=np.uint32)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
+        # every rank holds all N single sizes although it computed only those of its own block
+        assert np.array_equal(np.load(tmp_path / f"singles_{r}.npy"), want_singles)
+        asked = np.load(tmp_path / f"asked_{r}.npy").tolist()
+        assert asked == ([list(blocks[r])] if blocks[r][1] > blocks[r][0] else [])
         rows = np.load(tmp_path / f"rows_{r}.npy")
         for a, b in rows:
             assert blocks[r][0] <= a < b <= blocks[r][1]
@@ -193,6 +211,16 @@ class _CheckerContext:
         self.torch_device = torch.device("cpu")
         self.seqs = []
         self.closed = False
+        self.options = {}
+        self.singles_asked = []
+
+    def set_option(self, key, value):
+        self.options[key] = value
+
+    def singles_rows(self, r0, r1):
+        import oracle
+        self.singles_asked.append((r0, r1))
+        return np.array([oracle.lz4f_size(s) for s in self.seqs[r0:r1]], dtype=np.uint32)
 
     arena_limit = None           # residues one upload may hold (tests of the blocked path set it)
 
@@ -251,6 +279,7 @@ def _worker_cli(rank, world, port, fadir, outdir, arena_limit=None):
     Path(outdir, f"cli_{rank}.txt").write_text(f"{res.exit_code}\n{int(out.exists())}\n{int(dist.is_initialized())}\n"
                                                f"{int(made[0].closed)}\n{res.output}\n{res.exception!r}")
     Path(outdir, f"uploads_{rank}.txt").write_text(str(getattr(made[0], "uploads", 0)))
+    Path(outdir, f"asked_{rank}.txt").write_text(repr((made[0].options, made[0].singles_asked)))
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -275,6 +304,13 @@ def test_cli_multi_rank_only_rank0_reports_and_writes(tmp_path, world):
         assert ("Compressing pairs..." in "\n".join(output)) == (r == 0)
     got = np.loadtxt(tmp_path / "out_0.csv", delimiter=",", skiprows=1, usecols=range(1, 6))
     assert np.array_equal(got, want)
+    # phase A per owner: every rank deferred it at upload and asked for the singles of its own block of rows, once
+    from snacc_amd.distributed import lz4_row_weights, shard_rows_weighted
+    blocks = shard_rows_weighted(lz4_row_weights([len(s) for s in seqs]), world)
+    for r in range(world):
+        options, asked = eval((tmp_path / f"asked_{r}.txt").read_text())
+        assert options.get("defer_singles") == 1
+        assert asked == ([tuple(blocks[r])] if blocks[r][1] > blocks[r][0] else [])
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -305,6 +341,30 @@ def test_cli_multi_rank_set_beyond_one_upload_is_sharded_by_group_pairs(tmp_path
     assert sum(uploads) >= 10 and max(uploads) < sum(uploads)           # every rank took a share of the group pairs
     got = np.loadtxt(tmp_path / "out_0.csv", delimiter=",", skiprows=1, usecols=range(1, 8))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world", [2])
+def test_cli_multi_rank_pair_that_fits_no_upload_ends_every_rank(tmp_path, world):
+    """A single pair that fits no upload is met by ONE rank of the blocked path (the one dealt that group pair).  The ranks
+    agree on the failure before the data reduce: every rank ends with a non-zero status and a message, none blocks in the
+    collective, nothing is written."""
+    from conftest import write_fasta
+    fadir = tmp_path / "fa"
+    fadir.mkdir()
+    import oracle
+    # two files of 9 kB whose pair exceeds the 15 kB one upload holds, two small ones: groups {0}, {1}, {2, 3}; of the six
+    # group pairs only (0, 1) fails, and the round-robin deal gives it to rank 1 alone
+    for k, length in enumerate((9000, 9000, 1500, 1500)):
+        write_fasta(fadir / f"g{k}.fasta", [("r", bytes(oracle.lcg_genome(300 + k, length)).decode())])
+    port = 37500 + (os.getpid() * 3 + world) % 2000
+    mp.spawn(_worker_cli, args=(world, port, str(fadir), str(tmp_path), 15_000), nprocs=world, join=True)
+    texts = []
+    for r in range(world):
+        code, wrote, *output = (tmp_path / f"cli_{r}.txt").read_text().split("\n")
+        assert code != "0" and wrote == "0", (r, output)
+        texts.append("\n".join(output))
+    assert "do not fit one upload" in texts[1] and "do not fit one upload" not in texts[0]
+    assert "another rank could not compute" in texts[0]
 
 
 def test_blocked_sizes_splits_an_upload_that_still_does_not_fit(tmp_path):

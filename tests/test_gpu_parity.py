@@ -32,6 +32,51 @@ def _check_all(hip, oracle, seqs, **opts):
     return packed
 
 
+def test_phase_a_on_demand_per_row_and_spread_over_the_card(hip, oracle_mod):
+    """Round 4: (a) phase A spreads its N jobs over every wave of the card and runs the two-lane loop (fast_spec=0: the
+    one-lane loop; fast_lanes: the old packed geometry) -- same sizes and the same snapshots (the pairs that start from them);
+    (b) option defer_singles: the upload leaves phase A to the calls that need it -- snk_singles_rows for a block of rows,
+    snk_pairs / snk_pairs_list for the prefixes they compute -- on a set that mixes 2-bit sequences (with and without
+    exception sites), byte-kernel sequences and one-shot inputs; (c) snk_upload_times reports the upload's stages."""
+    o = oracle_mod
+    nrun = np.frombuffer(bytes(o.lcg_genome(41, 150000)).replace(b"ACGTA", b"ACNTA"), dtype=np.uint8)
+    seqs = [o.lcg_genome(31 + i, 140000 + 9001 * i) for i in range(5)] + [nrun, o.lcg_genome(51, 30000),
+            np.frombuffer(lcg_bytes(32, 90000, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8), o.lcg_genome(52, 70000)]
+    n = len(seqs)
+    exp_s = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
+    exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+    pure = [o.lcg_genome(61 + i, 200000 + 4099 * i) for i in range(7)]
+    exp_ps = np.array([o.lz4f_size(x) for x in pure], dtype=np.uint32)
+    exp_pp = np.array([[o.lz4f_size_pair(a, b) for b in pure] for a in pure], dtype=np.uint32)
+    for opts in ({}, {"fast_spec": 0}, {"fast_lanes": 3}, {"fast_lanes": 21, "fast_spec": 0}):
+        with hip.HipContext(0, **opts) as ctx:
+            ctx.upload(pure)
+            assert np.array_equal(ctx.singles(), exp_ps), opts
+            assert np.array_equal(ctx.pairs(), exp_pp), opts
+            t = ctx.upload_times()
+            assert t["total"] > 0 and t["singles"] > 0 and abs(sum(v for k, v in t.items() if k != "total") - t["total"]) < 0.05
+        with hip.HipContext(0, **opts) as ctx:
+            ctx.upload(seqs)
+            assert np.array_equal(ctx.singles(), exp_s), opts
+            assert np.array_equal(ctx.pairs(), exp_p), opts
+    with hip.HipContext(0, defer_singles=1) as ctx:
+        ctx.upload(seqs)
+        assert ctx.upload_times()["singles"] == 0.0
+        assert np.array_equal(ctx.singles_rows(2, 5), exp_s[2:5])             # a block of rows: their phase A runs now
+        assert np.array_equal(ctx.pairs(2, 5), exp_p[2:5])
+        assert np.array_equal(ctx.pairs(5, 7), exp_p[5:7])                    # rows nobody asked the singles of: pairs run it
+        ij = [(8, 0), (0, 8), (7, 7), (1, 6)]
+        assert ctx.pairs_list(ij).tolist() == [int(exp_p[i, j]) for i, j in ij]      # ... and so does a pair list, per prefix
+        assert np.array_equal(ctx.singles(), exp_s)                           # the rest
+        assert np.array_equal(ctx.pairs(), exp_p)
+    with hip.HipContext(0, defer_singles=1) as ctx:                           # gzip / zlib never run the lz4 pass
+        ctx.upload(seqs[:4])
+        from oracle import deflate as dfl
+        assert [int(v) for v in ctx.deflate_singles("zlib")] == [dfl.zlib_size(x) for x in seqs[:4]]
+        assert ctx.upload_times()["singles"] == 0.0
+        assert np.array_equal(ctx.singles(), exp_s[:4])                       # (still there when asked for)
+
+
 def test_tiny_and_empty_inputs(hip, oracle_mod):
     seqs = [b"ACGT" * 10, b"ACGTTGCA" * 3, b"A", b"", b"ACGTN" * 5, b"GATTACA" * 1000, b"ACGTACGTACGTA", b"ACGTACGTACGT"]
     _check_all(hip, oracle_mod, seqs)
@@ -1014,7 +1059,7 @@ def test_bench_line_keeps_the_driver_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--genomes", "128", "--steps", "2", "--warmup", "1",
-                          "--no-matrix", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--cpu-seconds", "1", "--no-cli-wall"], capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -1030,3 +1075,15 @@ def test_bench_line_keeps_the_driver_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["parity_spot_check"] is True
+    # the measured full matrix with its serial share, and the strong-scaling figure beside the weak one
+    m = d["matrix"]
+    assert m["symmetric"] is True and 0 < m["fixed_s"] < m["matrix_wall_s"] and m["upload_stages_s"]["total"] > 0
+    assert abs(m["fixed_s"] - (m["upload_and_singles_s"] + m["ncd_assembly_s"])) < 1e-9
+    assert d["strong"]["n_gpus"] == 1 and d["strong"]["pair_compressions_per_s"] > 0
+    # the secondary legs run under the same clock, each with a true spot check against the oracle
+    sec = d["secondary"]
+    assert sorted(sec) == ["gzip", "markov", "related", "softmask5", "zlib"], sec
+    for name, leg in sec.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["parity_spot_check"] is True and leg["pair_compressions_per_s"] > 0 and leg["kernel_ms_avg"] > 0, (name, leg)
+        assert abs(leg["roofline"]["frac"] - leg["roofline"]["achieved"] / 8000.0) < 1e-12 and "traffic" in leg["roofline"]

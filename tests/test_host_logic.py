@@ -125,6 +125,66 @@ def test_ncd_matrix_equals_scalar_formula():
     assert np.array_equal(m, m.T)
 
 
+def test_native_ncd_assembly_equals_the_numpy_statement_and_the_scalar_formula():
+    """snk_ncd_matrix_u32 (the library's host threads; what cli.gpu_matrix and bench.py's matrix run call on the raw uint32
+    sizes) is bit-equal to matrix.ncd_matrix -- and through it to the reference's compute_distance -- over tile edges (63 / 64 /
+    65 / 129 sequences), equal sizes off the diagonal, the smallest and largest sizes the kernels return, and both overheads
+    (33 = getsizeof alone; gzip's sizes carry their wrapper bytes already)."""
+    from snacc_amd import hip_backend
+    from snacc_amd.matrix import ncd_matrix_raw
+    assert hip_backend.load() is not None, "libsnacc_hip.so must load (host code: no GPU needed)"
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 17, 63, 64, 65, 129, 300):
+        s = rng.integers(11, 600000, n).astype(np.uint32)
+        p = rng.integers(11, 1300000, (n, n)).astype(np.uint32)
+        if n > 5:
+            s[3] = s[5]
+            p[0, 1] = 0xFFFFFFF0
+            s[2] = 0xFFFFFF00
+        for overhead in (33, 0):
+            if overhead == 0 and n == 1:
+                continue
+            got = ncd_matrix_raw(s, p, overhead)
+            want = ncd_matrix(s.astype(np.int64) + overhead, p.astype(np.int64) + overhead)
+            assert got.dtype == np.float64 and got.tobytes() == want.tobytes(), (n, overhead)
+        if n == 17:
+            m = ncd_matrix_raw(s, p)
+            for i, j in itertools.product(range(n), repeat=2):
+                assert m[i, j] == compute_distance(int(s[i]) + 33, int(s[j]) + 33, int(p[i, j]) + 33, int(p[j, i]) + 33)
+    # other dtypes / shapes take the numpy statement (same numbers)
+    s64 = np.array([100, 200], dtype=np.int64)
+    p64 = np.array([[150, 260], [250, 330]], dtype=np.int64)
+    assert np.array_equal(ncd_matrix_raw(s64, p64, 0), ncd_matrix(s64, p64))
+    assert ncd_matrix_raw(np.zeros(0, np.uint32), np.zeros((0, 0), np.uint32)).shape == (0, 0)
+
+
+def test_csv_writer_formats_in_row_chunks(tmp_path, monkeypatch):
+    """The float fields are formatted CSV_CHUNK_ROWS rows at a time into one reused buffer (never the text of the whole
+    matrix at once); chunk edges do not show in the file, and a failed allocation falls back to the Python statement."""
+    import snacc_amd.cli as cli_mod
+    rng = np.random.default_rng(9)
+    n = 23
+    m = 0.9 + 0.2 * rng.random((n, n))
+    files = [Path(f"/d/g{i:03d}.fa") for i in range(n)]
+    ref = tmp_path / "ref.csv"
+    write_matrix_csv_python(files, m, ref)
+    for chunk in (1, 5, 23, 256):
+        monkeypatch.setattr(cli_mod, "CSV_CHUNK_ROWS", chunk)
+        out = tmp_path / f"c{chunk}.csv"
+        write_matrix_csv(files, m, out)
+        assert out.read_bytes() == ref.read_bytes(), chunk
+    real = cli_mod._csv_row_formatter
+
+    def failing():
+        def fmt(rows):
+            raise MemoryError
+        return fmt if real() is not None else None
+    monkeypatch.setattr(cli_mod, "_csv_row_formatter", failing)
+    out = tmp_path / "fallback.csv"
+    write_matrix_csv(files, m, out)
+    assert out.read_bytes() == ref.read_bytes()
+
+
 @pytest.mark.parametrize("set_name", ["acgt_small", "ragged_blocks"])
 @pytest.mark.parametrize("rc", [False, True])
 def test_csv_from_oracle_sizes_matches_reference_cli(golden, oracle_mod, tmp_path, set_name, rc):
