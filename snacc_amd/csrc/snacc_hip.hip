@@ -8,7 +8,10 @@
 #include "snk_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -132,6 +135,97 @@ template <typename T> struct DevTemp {
     void release() { if (p) { (void)hipFree((void *)p); p = nullptr; } }
 };
 
+// ---- host-to-device copy of the ASCII arena through pinned staging buffers ------------------------------------------
+// The caller's sequences are pageable memory: one hipMemcpy per sequence moves 1 GB in ~55-85 ms (1024 calls, the runtime's
+// own staging at 12-18 GB/s).  Here SNK_STAGE_THREADS host threads build the arena image -- the sequences back to back at
+// their offsets, the zero padding between them included -- chunk by chunk in pinned buffers (two per thread, so that a
+// thread fills one while the DMA engine drains the other) and send every chunk with one asynchronous copy on the thread's own
+// stream.  Buffers, streams and events are a process-wide pool (allocated at the first upload, per device).
+#define SNK_STAGE_THREADS 6
+#define SNK_STAGE_CHUNK   ((size_t)4 << 20)
+struct SnkStagePool {
+    std::mutex mu;                 // one staged upload at a time per process (contexts are independent otherwise)
+    int device = -1;
+    void *buf[SNK_STAGE_THREADS][2] = {};
+    hipStream_t st[SNK_STAGE_THREADS] = {};
+    hipEvent_t ev[SNK_STAGE_THREADS][2] = {};
+};
+SnkStagePool g_stage;
+
+// (called with g_stage.mu held)
+hipError_t stage_pool_prepare(int device)
+{
+    SnkStagePool &P = g_stage;
+    if (P.device == device) return hipSuccess;
+    for (int t = 0; t < SNK_STAGE_THREADS; ++t) {          // another device (or first use): rebuild
+        for (int b = 0; b < 2; ++b) {
+            if (P.buf[t][b]) { (void)hipHostFree(P.buf[t][b]); P.buf[t][b] = nullptr; }
+            if (P.ev[t][b]) { (void)hipEventDestroy(P.ev[t][b]); P.ev[t][b] = nullptr; }
+        }
+        if (P.st[t]) { (void)hipStreamDestroy(P.st[t]); P.st[t] = nullptr; }
+    }
+    P.device = -1;
+    for (int t = 0; t < SNK_STAGE_THREADS; ++t) {
+        hipError_t e = hipStreamCreateWithFlags(&P.st[t], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        for (int b = 0; b < 2; ++b) {
+            e = hipHostMalloc(&P.buf[t][b], SNK_STAGE_CHUNK, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            e = hipEventCreateWithFlags(&P.ev[t][b], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+    }
+    P.device = device;
+    return hipSuccess;
+}
+
+// d_bytes[0, btot) = the arena image of the sequences (seqs[g] at boff[g], zeros elsewhere).  Blocking.
+hipError_t stage_upload(int device, uint8_t *d_bytes, size_t btot, size_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                        const std::vector<size_t> &boff)
+{
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    hipError_t e0 = stage_pool_prepare(device);
+    if (e0 != hipSuccess) return e0;
+    const size_t nchunks = (btot + SNK_STAGE_CHUNK - 1) / SNK_STAGE_CHUNK;
+    const int nt = (int)std::min<size_t>(SNK_STAGE_THREADS, nchunks);
+    std::atomic<int> err((int)hipSuccess);
+    auto work = [&](int t) {
+        SnkStagePool &P = g_stage;
+        if (hipSetDevice(device) != hipSuccess) { err = (int)hipErrorInvalidDevice; return; }
+        bool used[2] = { false, false };
+        int b = 0;
+        for (size_t k = (size_t)t; k < nchunks && err.load() == (int)hipSuccess; k += (size_t)nt, b ^= 1) {
+            const size_t a = k * SNK_STAGE_CHUNK, e = std::min(btot, a + SNK_STAGE_CHUNK);
+            if (used[b]) { const hipError_t r = hipEventSynchronize(P.ev[t][b]); if (r != hipSuccess) { err = (int)r; return; } }
+            uint8_t *dst = (uint8_t *)P.buf[t][b];
+            // first sequence whose slot reaches into [a, e): slots are in offset order
+            size_t g = (size_t)(std::upper_bound(boff.begin(), boff.end(), a) - boff.begin());
+            if (g > 0) --g;
+            size_t pos = a;                                    // arena bytes [a, pos) of the chunk are written
+            for (; g < n && boff[g] < e; ++g) {
+                const size_t s0 = boff[g], s1 = boff[g] + (size_t)lens[g];
+                const size_t c0 = std::max(s0, pos), c1 = std::min(s1, e);
+                if (c1 <= c0) continue;
+                if (c0 > pos) memset(dst + (pos - a), 0, c0 - pos);
+                memcpy(dst + (c0 - a), seqs[g] + (c0 - s0), c1 - c0);
+                pos = c1;
+            }
+            if (e > pos) memset(dst + (pos - a), 0, e - pos);
+            hipError_t r = hipMemcpyAsync(d_bytes + a, dst, e - a, hipMemcpyHostToDevice, P.st[t]);
+            if (r == hipSuccess) r = hipEventRecord(P.ev[t][b], P.st[t]);
+            if (r != hipSuccess) { err = (int)r; return; }
+            used[b] = true;
+        }
+        const hipError_t r = hipStreamSynchronize(P.st[t]);
+        if (r != hipSuccess) err = (int)r;
+    };
+    std::vector<std::thread> ts;
+    for (int t = 1; t < nt; ++t) ts.emplace_back(work, t);
+    work(0);
+    for (auto &th : ts) th.join();
+    return (hipError_t)err.load();
+}
+
 void free_sequences(snk_ctx_impl *c)
 {
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_pmask); dfree(c->d_slots); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
@@ -246,15 +340,21 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
 {
     SnkTables T = make_tables(c);
     if (n_fast) {
-        const uint32_t waves = (uint32_t)c->fast_waves;
+        uint32_t waves = (uint32_t)c->fast_waves;
         const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
         uint32_t lanes = 0;
         if (fast_geometry(c, &lanes) != SNK_OK) return SNK_E_ARG;
         if (singles && c->fast_lanes == 0) {
-            // phase A has N jobs, not N^2: spread them over every wave of the card (1024 sequences on 256 CUs: one chain per
-            // wave) instead of filling 84-chain workgroups on a few CUs -- the pass then takes one chain's serial parse
-            const uint64_t wv = (uint64_t)std::max(c->n_cus, 1) * waves;
-            lanes = std::min<uint32_t>(lanes, (uint32_t)std::max<uint64_t>(1u, (n_fast + wv - 1u) / wv));
+            // Phase A has N jobs, not N^2, and no two of them share a byte: what counts is one chain's serial parse.  Measured
+            // (tools/gpu_singles.py, tools/gpu_geom.py, 1024 x 1 Mbp): 84-chain workgroups on 13 CUs 85 ms (one lane per chain) /
+            // 62 ms (two); spread over all CUs as 4 waves x 1 chain 92 ms -- waves with fewer than ~8 chains slow each other
+            // down when several share a CU (1 / 2 / 3 / 4 waves of 1 chain: 44 / 60 / 76 / 87 ms per round, waiting for
+            // instruction issue by the SQ counters; 8 chains per wave and more: no such effect) -- and as ONE wave per CU with
+            // ceil(N / CUs) chains 48 ms.  So: one wave per workgroup while 21 chains per CU cover the jobs, more waves beyond.
+            const uint64_t cus = (uint64_t)std::max(c->n_cus, 1);
+            const uint32_t full = lanes;                                  // chains per wave the LDS allows at c->fast_waves
+            waves = (uint32_t)std::min<uint64_t>(waves, std::max<uint64_t>(1u, (n_fast + cus * full - 1u) / (cus * full)));
+            lanes = std::min<uint32_t>(full, (uint32_t)std::max<uint64_t>(1u, (n_fast + cus * waves - 1u) / (cus * waves)));
         }
         const uint32_t chains = lanes * waves;
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
@@ -865,10 +965,7 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     const uint32_t lcase = c->lower ? 0x20u : 0u;                 // ORed into 'A' 'C' 'G' 'T': the set's four letters
 
     HIPCHK(c, hipMalloc((void **)&c->d_bytes, btot));
-    HIPCHK(c, hipMemsetAsync(c->d_bytes, 0, btot, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t g = 0; g < n; ++g)
-        if (lens[g]) HIPCHK(c, hipMemcpy(c->d_bytes + boff[g], seqs[g], lens[g], hipMemcpyHostToDevice));
+    HIPCHK(c, stage_upload(c->device, c->d_bytes, btot, n, seqs, lens, boff));       // every byte of the arena, padding included
 
     c->up_ms[0] = up_lap();
 
@@ -1142,7 +1239,7 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
         const int rc = ensure_singles(c, 0, n_seq);        // phase A for every sequence, as part of the upload
         if (rc) return rc;
     }
-    c->up_ms[5] = up_lap();
+    c->up_ms[5] = c->defer_singles ? 0.0 : up_lap();
     c->up_ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - up_t0).count();
     return SNK_OK;
 }

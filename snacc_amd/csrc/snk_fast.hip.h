@@ -1688,7 +1688,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
     const uint32_t waves = blockDim.x >> 6;
 
 #ifdef SNK_STATS
-    const unsigned long long stat_w0 = clock64();
+    const unsigned long long stat_w0 = clock64(), stat_wall0 = wall_clock64();      // (wall clock: constant 100 MHz -> the shader clock of the run)
     SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
@@ -1814,7 +1814,8 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 #ifdef SNK_STATS
             if (lane == 0u) {
                 unsigned long long *S = snk_stats + (FAR ? 32 : 0);
-                atomicAdd(&S[7], clock64() - stat_w0);
+                atomicAdd(&S[7], clock64() - stat_w0); atomicAdd(&S[51], wall_clock64() - stat_wall0);
+                atomicMax(&S[52], wall_clock64() - stat_wall0); atomicMax(&S[53], ~stat_wall0); atomicMax(&S[54], wall_clock64());   // longest wave, first start, last end
                 atomicAdd(&S[13], P.loop); atomicAdd(&S[14], (unsigned long long)P.entries);
                 atomicAdd(&S[24], P.finish); atomicAdd(&S[25], P.rounds_cyc); atomicAdd(&S[26], (unsigned long long)P.rounds);
                 atomicAdd(&S[27], P.prologue); atomicAdd(&S[28], P.probe); atomicAdd(&S[29], P.top);

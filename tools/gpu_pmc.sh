@@ -1,13 +1,13 @@
 #!/bin/bash
 # Dev aid (GPU box): SQ / LDS / TCP counters of one snk_fast_kernel launch, one rocprofv3 --pmc pass per group.
-# Usage: tools/gpu_pmc.sh OUTDIR [N L ROWS]   (summaries: OUTDIR/pmc_<group>.json)
+# Usage: [LANES=21 WAVES=4] tools/gpu_pmc.sh OUTDIR [N L ROWS]   (summaries: OUTDIR/pmc_<group>.json)
 set -u
 OUT=${1:-gpurun_out/pmc}; N=${2:-1024}; L=${3:-1000000}; R=${4:-84}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 run() {   # group name, counters...
   g=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/raw_$g" -- python3 tools/gpu_prof.py $N $L $R 21 4 > "$OUT/run_$g.log" 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/raw_$g" -- python3 tools/gpu_prof.py $N $L $R ${LANES:-21} ${WAVES:-4} > "$OUT/run_$g.log" 2>&1
   f=$(find "$OUT/raw_$g" -name '*counter_collection.csv' | head -1)
   python3 - "$f" "$g" > "$OUT/pmc_$g.json" <<'PY'
 import csv, sys, json, collections
