@@ -1919,7 +1919,10 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
             P.jobs += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(stat_done));
             P.probe += clock64() - stat_g0;                                                 // inside the general probes
 #endif
-            if (!dry && __any(lane_on && !have)) { refill = true; break; }
+            // (a finished lane goes back to the hand-out -- unless that would hold it anyway: sets with exceptions hand the next
+            // batch out only when the wave's whole batch has ended, and a pass through the top of the loop for nothing re-runs
+            // the ballots and the gathering logic and ages `waiting`)
+            if (!dry && __any(lane_on && !have) && !(EXC && wb >= we && __any(have))) { refill = true; break; }
         }
 #ifdef SNK_STATS
         P.rounds_cyc += clock64() - stat_i0;
