@@ -1,12 +1,22 @@
-"""Dev aid: one upload + one pairs() launch, for rocprofv3.  Usage: _gpu_prof.py N L ROWS LANES WAVES"""
+"""Dev aid: one upload + one pairs() launch, for rocprofv3.  Usage: [DATA=lcg|markov|related|softmask5] gpu_prof.py N L ROWS LANES WAVES"""
+import os
 import sys
 sys.path.insert(0, '.')
 import numpy as np
-from bench import lcg_genomes_torch
+import bench
 import torch
 from snacc_amd.hip_backend import HipContext
 N, L, R, lanes, waves = map(int, sys.argv[1:6])
-seqs = lcg_genomes_torch(N, L, 1, torch.device('cuda', 0))
+data = os.environ.get("DATA", "lcg")
+dev = torch.device('cuda', 0)
+if data == "markov":
+    seqs = bench.markov_genomes_torch(N, L, dev)
+elif data == "related":
+    seqs = bench.lcg_related_torch(N, L, dev)
+elif data.startswith("softmask"):
+    seqs = bench.softmask_genomes(bench.lcg_genomes_torch(N, L, 1, dev), int(data[8:]))
+else:
+    seqs = bench.lcg_genomes_torch(N, L, 1, dev)
 ctx = HipContext(0, fast_lanes=lanes, fast_waves=waves)
 ctx.upload(seqs)
 p = ctx.pairs(0, R)

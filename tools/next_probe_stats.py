@@ -80,3 +80,35 @@ while i < len(ps) - 3:
     k = 2 if (ps[i][1] and ps[i+1][0] - ps[i][0] == 5) else 1
     i += k; trips += 1
 print("probes per trip, depth 2:", len(ps) / trips)
+# round 4: three lanes per chain -- which second speculation pays more?  (a) role 2 at cur+10 (counts when two 5-base matches
+# follow each other), (b) role 2 at cur+6 (counts when role 0's match ends at cur+6 and role 1's probe does not count),
+# (c) both (four lanes).  Greedy grouping as above: a trip consumes the probes that counted.
+def per_trip(use10, use6):
+    i = 0; trips = 0
+    while i < len(ps) - 3:
+        k = 1
+        d1 = ps[i + 1][0] - ps[i][0]
+        if ps[i][1] and d1 == 5:
+            k = 2
+            if use10 and ps[i + 1][1] and ps[i + 2][0] - ps[i + 1][0] == 5: k = 3
+        elif use6 and ps[i][1] and d1 == 6:
+            k = 2
+        i += k; trips += 1
+    return len(ps) / trips
+print("probes per trip: lanes at +5: %.3f; +5,+10: %.3f; +5,+6: %.3f; +5,+6,+10: %.3f" % (per_trip(False, False), per_trip(True, False), per_trip(False, True), per_trip(True, True)))
+# ... and when the speculation after a NON-match (next probe at cur+1: a search probe, nothing owed) is served too
+def per_trip2(use10, use6, use1):
+    i = 0; trips = 0
+    while i < len(ps) - 3:
+        k = 1
+        d1 = ps[i + 1][0] - ps[i][0]
+        if ps[i][1] and d1 == 5:
+            k = 2
+            if use10 and ps[i + 1][1] and ps[i + 2][0] - ps[i + 1][0] == 5: k = 3
+        elif use6 and ps[i][1] and d1 == 6:
+            k = 2
+        elif use1 and (not ps[i][1]) and d1 == 1:
+            k = 2
+        i += k; trips += 1
+    return len(ps) / trips
+print("with a lane at +1 as well: +5,+1: %.3f; +5,+6,+1: %.3f; +5,+10,+1: %.3f" % (per_trip2(False, False, True), per_trip2(False, True, True), per_trip2(True, False, True)))
