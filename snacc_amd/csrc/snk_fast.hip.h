@@ -721,7 +721,26 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 #else
 #define SNK_PADE
 #endif
+// The asm contract, as a comment in the generated code (tests/test_asm_contract.py compiles this file with -S and reads it
+// back): which registers the compiler gave the read-write operands and which the input-only ones.  The two sets must not
+// meet -- the read-write operands are not early-clobber (that numbering runs 2 % slower: operand banks), so an input-only
+// operand whose value the compiler can prove equal to a read-write operand's at entry may be given the SAME register, which
+// the loop then overwrites (round 3 hit exactly that with a zero mask beside sl = 0).  No instruction, no cost.
+#ifdef SNK_PARK
+#define SNK_CONTRACT_BLK " %[blk]"
+#define SNK_OPERAND_BLK , [blk] "s"(blk)
+#else                                   /* (the parking mask exists in the diagnostic build only: no operand in the shipped loop) */
+#define SNK_CONTRACT_BLK
+#define SNK_OPERAND_BLK
+#endif
+#define SNK_STEADY_CONTRACT \
+    "; snk-asm-contract inout %[c] %[wc] %[s1] %[s2] %[r0] %[r1] %[rbc] %[nxoff] %[anchor] %[op] %[opn] %[ns2] %[sm] %[sl]" \
+    " | in %[lb] %[sx] %[kx] %[xoffB] %[yoffB] %[T0] %[limc] %[oz] %[dm] %[k8] %[arena] %[marena]" SNK_CONTRACT_BLK "\n\t"
+#define SNK_STEADY_CONTRACT_FAR \
+    "; snk-asm-contract inout %[c] %[wc] %[s1] %[s2] %[r0] %[r1] %[rbc] %[nxoff] %[anchor] %[op] %[opn] %[ns2] %[sm] %[sl]" \
+    " | in %[lb] %[sx] %[kx] %[xoffB] %[yoffB] %[T0] %[limc] %[oz] %[dm] %[k8] %[arena] %[marena]" SNK_CONTRACT_BLK " %[gtb] %[ftab] %[vbm2] %[k17]\n\t"
 #define SNK_STEADY_TABLE \
+    SNK_STEADY_CONTRACT \
     SNK_STEADY_ENTER \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
@@ -757,6 +776,7 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 #define SNK_FAR_LOADMOD "sc1"      /* device scope: served by the L2, the line is not kept in the CU's L1 (which the windows of y live in) */
 #endif
 #define SNK_STEADY_TABLE_FAR \
+    SNK_STEADY_CONTRACT_FAR \
     SNK_STEADY_ENTER \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur */ \
@@ -928,7 +948,7 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
       [t] "=&v"(t), [lit] "=&v"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [se] "=&s"(se) \
     : [lb] "v"(lds_off), [sx] "v"(sx), [kx] "v"(kx), [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), \
       [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(dm), [k8] "s"(0x00800000u), \
-      [arena] "s"(arena), [marena] "s"(marena), [blk] "s"(blk) __VA_ARGS__ \
+      [arena] "s"(arena), [marena] "s"(marena) SNK_OPERAND_BLK __VA_ARGS__ \
     : "memory", "vcc", "scc", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
@@ -1235,7 +1255,11 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "v_add_u32_e32 v102, 0xfffb, %[c]\n\t" \
     "v_add_u32_e32 v103, 0xfff9, %[c]\n\t" \
     "v_add_u32_e32 v127, 0xfffe, %[c]\n\t"
+#define SNK_SPEC_CONTRACT \
+    "; snk-asm-contract inout %[c] %[wc] %[s1] %[s2] %[r0] %[r1] %[rbc] %[nxoff] %[anchor] %[op] %[opn] %[ns2] %[sm] %[sl] %[scm] %[sc0] %[sq] %[sc]" \
+    " | in %[lb] %[five] %[fivec] %[sx] %[kx] %[xoffB] %[yoffB] %[T0] %[limc] %[oz] %[dm] %[k8] %[arena] %[marena] %[r1m] %[vz]\n\t"
 #define SNK_SPEC_TABLE \
+    SNK_SPEC_CONTRACT \
     "s_mov_b64 %[ex], exec\n\t"                         /* the lanes of the loop */ \
     SNK_SPEC_CURS \
     "1:\n\t" \

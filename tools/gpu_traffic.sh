@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/r02_pmc_traffic.json}; COMMIT=${2:?COMMIT (tools/commit_id.s
 export TMPDIR=/tmp
 D=$(dirname "$OUT")/traffic_raw; mkdir -p "$D"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$D/$c" -- python3 tools/gpu_prof.py $N $L $R 21 4 > "$D/$c.log" 2>&1
+  rocprofv3 --pmc $c --kernel-include-regex "snk_" --output-format csv -d "$D/$c" -- python3 tools/gpu_prof.py $N $L $R 21 4 > "$D/$c.log" 2>&1
 done
 python3 - "$D" "$OUT" "$COMMIT" $N $L $R "${DATA:-lcg}" "${KERNEL:-snk_fast_kernel}" <<'PY'
 import csv, glob, json, sys
