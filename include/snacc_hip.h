@@ -104,7 +104,9 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   (py-lz4framed builds that set it)
  *   "fast_asm"      1 (default) = the hand-scheduled steady loop of the 2-bit kernel; 0 = its C++ statement (cross-checks)
  *   "fast_spec"     1 (default) = two lanes per chain in the 2-bit kernel's steady loop (snk_fast_steady_spec: the second
- *                   lane probes 5 bases ahead; exact); 0 = one lane per chain
+ *                   lane probes 5 bases ahead; exact); 0 = one lane per chain; 3 / 36 = three lanes per chain as a C++
+ *                   statement (a third lane 10 / 6 bases ahead; 20 chains per wave; pure-ACGT sets; exact) -- built and
+ *                   measured negative in round 4 (profiles/r04_third_lane.json), kept for reproduction
  *   "defer_singles" 1 = snk_upload / snk_upload_fasta leave phase A (single sizes + prefix snapshots) to the calls that
  *                   need it: snk_singles / snk_singles_rows for the rows asked for, the snk_pairs* calls for the rows
  *                   (prefixes) they compute.  A rank of a row-sharded run thus computes its own rows only, and a

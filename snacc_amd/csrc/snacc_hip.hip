@@ -53,7 +53,8 @@ struct snk_ctx_impl {
 
     // options
     bool fast_asm = true;            // 0 = the C++ statement of the 2-bit kernel's steady loop (cross-checks)
-    bool fast_spec = true;           // pure-ACGT pair launches run with two lanes per chain (snk_fast_steady_spec); 0 = one lane
+    int fast_spec = 1;               // pair launches run with two lanes per chain (snk_fast_steady_spec); 0 = one lane; 3 = three
+                                     // lanes, C++ statement (snk_fast_steady_spec3: round 4 experiment, pure-ACGT sets)
     int fast_lanes = 0, fast_waves = 4, gen_chains = 8, bytes_lanes = 9, bytes_waves = 2;   // fast_lanes 0 = as many as the LDS holds
     int cbytes_lanes = 17, cbytes_waves = 4;   // compact byte kernel, 1024 slots: up to 70 chains per CU
     int c2bytes_lanes = 17, c2bytes_waves = 2; // compact byte kernel, 2048 slots: up to 35 chains per CU
@@ -356,6 +357,8 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             waves = (uint32_t)std::min<uint64_t>(waves, std::max<uint64_t>(1u, (n_fast + cus * full - 1u) / (cus * full)));
             lanes = std::min<uint32_t>(full, (uint32_t)std::max<uint64_t>(1u, (n_fast + cus * waves - 1u) / (cus * waves)));
         }
+        const bool tri = (c->fast_spec == 3 || c->fast_spec == 36) && !exc && !singles && c->far_lanes == 0;     // three lanes per chain: 5 chains per 16-lane row
+        if (tri && lanes > 20u) lanes = 20u;
         const uint32_t chains = lanes * waves;
         const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
         SnkFastGrid G;
@@ -366,11 +369,12 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
-        const bool spec = c->fast_spec && far_waves == 0u && lanes <= 32u;       // two lanes per chain
+        const bool spec = c->fast_spec != 0 && far_waves == 0u && lanes <= 32u;       // two lanes per chain
         const void *fk = singles ? (exc ? (spec ? (const void *)snk_fastx_singles_kernel : (const void *)snk_fastx_singles_one_kernel)
                                         : (spec ? (const void *)snk_fast_singles_kernel : (const void *)snk_fast_singles_one_kernel))
                        : exc ? (spec ? (c->fast_asm ? (const void *)snk_fastx_kernel : (const void *)snk_fastx_spec_cxx_kernel)
                                      : (c->fast_asm ? (const void *)snk_fastx_one_kernel : (const void *)snk_fastx_cxx_kernel))
+                             : tri ? (c->fast_spec == 36 ? (const void *)snk_fast_tri6_cxx_kernel : (const void *)snk_fast_tri_cxx_kernel)
                              : (spec ? (c->fast_asm ? (const void *)snk_fast_kernel : (const void *)snk_fast_spec_cxx_kernel)
                                      : (c->fast_asm ? (const void *)snk_fast_one_kernel : (const void *)snk_fast_cxx_kernel));
         HIPCHK(c, hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -806,7 +810,8 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         if (value < 0 || value > 10000) return fail(c, SNK_E_ARG, "far_stop_pct must be 0..10000");
         c->far_stop_pct = (int)value;
     } else if (k == "fast_spec") {
-        c->fast_spec = value != 0;
+        if (value != 0 && value != 1 && value != 3 && value != 36) return fail(c, SNK_E_ARG, "fast_spec must be 0, 1, 3 or 36");
+        c->fast_spec = (int)value;
     } else if (k == "defer_singles") {
         c->defer_singles = value != 0;
     } else if (k == "fast_asm") {

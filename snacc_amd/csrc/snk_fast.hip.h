@@ -1626,6 +1626,186 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     if (EXC) snk_fast_exc_handover(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     else     snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
 }
+
+// ---- three lanes per chain (round 4; C++ statement, option fast_spec = 3) -------------------------------------------------
+// Rows of 16 lanes hold 5 chains x 3 lanes (lane 15 of every row idles: 20 chains per wave): role 0 is the chain, role 1
+// probes 5 bases ahead as in snk_fast_steady_spec, role 2 TEN bases ahead -- where the chain stands when two 5-base matches
+// follow each other (42 % of the trips on genome data: 2.08 probes per chain-trip instead of 1.65, tools/next_probe_stats.py).
+// Role 2 reads the table with everybody; the four puts the chain would have made between the read and its probe -- role 0's
+// put(cur), role 1's put(cur+3) and put(cur+5), its own owed put(cur+8) -- are patched into what it read, latest first.  It
+// counts when role 1 counts AND role 1's probe is a 5-base match that needs no service; its two puts are then made at the top
+// of the next trip, after role 1's (liblz4's order).  Exactness never rests on a guess: a probe that does not count is dropped.
+// Values travel inside the row by DPP row shifts (row_shr:n -- lane l reads lane l-n of its row; row_shl:n -- lane l+n).
+__device__ __forceinline__ uint32_t snk_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t snk_row_shr2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x112, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t snk_row_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x101, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t snk_row_shl2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x102, 0xF, 0xF, true); }
+#define SNK_TRI_TAKE(v) do { const uint32_t a1_ = snk_row_shr1((uint32_t)(v)), a2_ = snk_row_shr2((uint32_t)(v)); \
+                             (v) = R == 1u ? a1_ : R == 2u ? a2_ : (v); } while (0)
+
+// P2 = 10: role 2 as described.  P2 = 6: the other placement -- role 2 probes SIX bases ahead and counts when role 0's match ends
+// there (17 % of the trips; role 1's then does not): its probe follows role 0's directly, so it is patched like role 1's
+// (role 0's put(cur), its own owed put) and at most one of the two probes ahead counts in a trip.
+template <uint32_t P2>
+__device__ __forceinline__ void snk_fast_steady_spec3(SnkFastLane &L, const uint32_t R, snk_g8 *const arena,
+                                                      uint16_t *tbl, uint32_t *bm SNK_PROF_ARG)
+{
+    static_assert(P2 == 10u || P2 == 6u, "role 2 probes 10 or 6 bases ahead");
+    const uint32_t ahead = R == 1u ? 5u : R == 2u ? P2 : 0u;          // this lane's cursor = the chain's + ahead
+#ifdef SNK_STATS
+    const unsigned long long stat_te = clock64();
+#endif
+    const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
+    // roles 1 and 2 take the chain's state at the loop entry from role 0
+    uint32_t vb = L.base, lx = L.s.lx, xoff = L.s.xoff, yoff = L.s.yoff, olimit = L.olimit;
+    uint32_t cur0 = L.cur, anchor0 = L.anchor, op = L.op, pend0 = L.pending ? 1u : 0u, wrb = L.w.rb, wsoff = L.w.soff, worg = L.w.org;
+    uint32_t lim_abs;
+    {
+        const uint32_t wlim = L.w.lim, limw = wlim == 0xFFFFFFFFu ? wlim : wlim + 1u;
+        lim_abs = L.mfl1 < limw ? L.mfl1 : limw;
+    }
+    SNK_TRI_TAKE(vb); SNK_TRI_TAKE(lx); SNK_TRI_TAKE(xoff); SNK_TRI_TAKE(yoff); SNK_TRI_TAKE(lim_abs);
+    SNK_TRI_TAKE(olimit); SNK_TRI_TAKE(cur0); SNK_TRI_TAKE(anchor0); SNK_TRI_TAKE(op); SNK_TRI_TAKE(pend0);
+    SNK_TRI_TAKE(wrb); SNK_TRI_TAKE(wsoff); SNK_TRI_TAKE(worg);
+
+    const int32_t T0 = (int32_t)(vb - 65536u);
+    const int32_t X0 = T0 - 4, Y0 = T0 - 4 - (int32_t)lx;
+    const uint32_t kx = (uint32_t)X0 & 3u;
+    const uint32_t xoffB = xoff + (uint32_t)(X0 >> 2), yoffB = yoff + (uint32_t)(Y0 >> 2);
+    const int32_t sx = (int32_t)lx - 11 - T0;
+    const uint32_t limc = lim_abs - vb;
+    const int32_t olimZ = (int32_t)olimit - (int32_t)SNK_FAST_ZONE + 10;
+    const uint32_t DUMMY = SNK_FSLOTS - 1u;
+    const uint32_t CM = 0x1FFFFFFFu;                               // cursor bits of the packed (next cursor, flags) word
+
+    uint32_t c = cur0 - vb + ahead;                                // this lane's cursor
+    uint32_t anchor_c = R ? c : anchor0 - vb;                      // roles 1 and 2 never have literals
+    uint32_t rbc = wrb + 4u - vb;
+    uint32_t nxoff = wsoff + ((wrb + 32u - worg) >> 2);
+    { const uint32_t sl = (c - rbc) >> 4; rbc += 16u * sl; nxoff += 4u * sl; }
+    uint32_t r0 = snk_ld4g(arena + (size_t)(nxoff - 8u)), r1 = snk_ld4g(arena + (size_t)(nxoff - 4u)), r2 = 0u;
+    uint32_t wc = __builtin_amdgcn_alignbit(r1, r0, 2u * (c - rbc));
+    uint32_t s1 = lut0[(wc >> 8) & 1023u];
+    uint32_t s2 = (R || pend0) ? (uint32_t)lut0[(wc >> 4) & 1023u] : DUMMY;
+    uint32_t d1 = DUMMY, d2 = DUMMY, dc = 2u;                     // roles 1 / 2: the puts of their probe of the last trip, if it counted
+    uint32_t t; bool valid;
+#ifdef SNK_STATS
+    const unsigned long long stat_t0 = clock64();
+    P.prologue += stat_t0 - stat_te;
+#endif
+    for (;;) {
+        // ---- the chain's table operations in liblz4's order: role 1's probe of the last trip (put, put), role 2's (put, put),
+        //      role 0's (put, get, put); roles 1 and 2 only read at their new cursors.  Nothing to write: the unused slot.
+        { const uint32_t x2 = R == 1u ? d2 : DUMMY, x1 = R == 1u ? d1 : DUMMY;
+          tbl[x2] = (uint16_t)(dc - 2u); atomicOr(&bm[x2 >> 5], 1u << (x2 & 31u));
+          tbl[x1] = (uint16_t)dc;        atomicOr(&bm[x1 >> 5], 1u << (x1 & 31u)); }
+        { const uint32_t x2 = R == 2u ? d2 : DUMMY, x1 = R == 2u ? d1 : DUMMY;
+          tbl[x2] = (uint16_t)(dc - 2u); atomicOr(&bm[x2 >> 5], 1u << (x2 & 31u));
+          tbl[x1] = (uint16_t)dc;        atomicOr(&bm[x1 >> 5], 1u << (x1 & 31u)); }
+        const uint32_t b2 = R ? DUMMY : s2, b1 = R ? DUMMY : s1;
+        tbl[b2] = (uint16_t)(c - 2u);  atomicOr(&bm[b2 >> 5], 1u << (b2 & 31u));
+        const uint32_t bit1 = s1 & 31u;
+        const uint32_t e = tbl[s1];
+        const uint32_t bw = atomicOr(&bm[s1 >> 5], (R ? 0u : 1u) << bit1);
+        tbl[b1] = (uint16_t)c;
+        t = e + (((bw >> bit1) & 1u) << 16);
+        {   // what the lanes before this one will have put by the time the chain reaches this lane's cursor (latest last)
+            const uint32_t a1s1 = snk_row_shr1(s1), a1s2 = snk_row_shr1(s2), a2s1 = snk_row_shr2(s1);
+            if (P2 == 10u) {
+                t = (R == 2u && a2s1 == s1) ? 65536u + c - 10u : t;      // role 0's put(cur)
+                t = (R == 2u && a1s2 == s1) ? 65536u + c - 7u : t;       // role 1's owed put(cur+3)
+                t = (R != 0u && a1s1 == s1) ? 65536u + c - 5u : t;       // the put(cursor) of the lane before
+            } else {
+                t = (R == 1u && a1s1 == s1) ? 65536u + c - 5u : t;       // role 0's put(cur), for either lane ahead
+                t = (R == 2u && a2s1 == s1) ? 65536u + c - 6u : t;
+            }
+            t = (R != 0u && s2 == s1) ? 65534u + c : t;                   // the own owed put
+        }
+        valid = t > c;
+
+        // ---- candidate window and the reservoir refill ----
+        const bool inx = (int32_t)t < sx;
+        const uint32_t tt = t + (inx ? kx : 0u);
+        const uint64_t v = snk_ld8g(arena + (size_t)((inx ? xoffB : yoffB) + (tt >> 2)));
+        r2 = snk_ld4g(arena + (size_t)nxoff);
+        const bool straddle = valid & ((uint32_t)((int32_t)t - sx) < 15u);
+        const uint32_t lit = c - anchor_c;
+        const uint32_t wd = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, 2u * (tt & 3u));
+
+        // ---- compare, this lane's next cursor, its account ----
+        const uint32_t x = wc ^ wd;
+        const uint32_t r = snk_ffbl(x >> 8);
+        const bool m = valid & (r >= 8u);
+        const uint32_t e2 = c + (r >> 1);
+        const uint32_t ncur = m ? e2 : c + 1u;
+        const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;
+        uint32_t b = eq < lit ? eq : lit;
+        { const uint32_t cand = (uint32_t)(T0 + (int32_t)t); b = b < cand ? b : cand; }
+        const uint32_t opn = op + (lit - b) + 3u;
+        int32_t mx = (int32_t)(b + 11u) > (int32_t)lit ? (int32_t)(b + 11u) : (int32_t)lit;
+        if (R == 0u) { const int32_t z = (int32_t)op - olimZ + 14 + 6; mx = mx > z ? mx : z; }     // (+6: two more sequences may be added in this trip)
+        const bool svc = (mx >= 15) | (ncur >= limc) | straddle | (e2 >= 0x10000000u);
+
+        // ---- the lanes of the chain decide: every lane offers "no service"; a lane's match "ends at +5" ----
+        // (bit 29: the match ends where the next lane probed -- for role 0 of the P2 = 6 form bit 28 says "6 bases on")
+        const bool end5 = m & ((r >> 1) == 5u), end6 = m & ((r >> 1) == 6u);
+        const uint32_t CMX = P2 == 6u ? 0x0FFFFFFFu : CM;
+        const uint32_t pk = (ncur & CMX) | ((P2 == 6u && end6) ? 0x10000000u : 0u) | (end5 ? 0x20000000u : 0u) | (m ? 0x40000000u : 0u) | (svc ? 0u : 0x80000000u);
+        const uint32_t A1 = snk_row_shr1(pk), A2 = snk_row_shr2(pk), B1 = snk_row_shl1(pk), B2 = snk_row_shl2(pk);
+        const uint32_t q0 = R == 0u ? pk : R == 1u ? A1 : A2;      // (next cursor, flags) of role 0 / 1 / 2, the same in all three lanes
+        const uint32_t q1 = R == 0u ? B1 : R == 1u ? pk : A1;
+        const uint32_t q2 = R == 0u ? B2 : R == 1u ? B1 : pk;
+        const bool com1 = ((q0 & 0xA0000000u) == 0xA0000000u) & ((int32_t)q1 < 0);           // role 1's probe counts
+        // role 2's counts when role 1's is a 5-base match too -- and the chain's advance stays within what every lane's
+        // 32-base reservoir can follow in one slide (16 bases: a role-2 match of up to 6)
+        const uint32_t c0 = c - ahead;
+        const bool com2 = P2 == 10u ? (com1 & ((q1 & 0x20000000u) != 0u) & ((int32_t)q2 < 0) & ((q2 & CM) - c0 <= 16u))
+                                    : (((q0 & 0x90000000u) == 0x90000000u) & ((int32_t)q2 < 0) & ((q2 & CMX) - c0 <= 16u));
+        const uint32_t nn = com2 ? q2 : com1 ? q1 : q0;
+        const uint32_t cp = nn & CMX;                             // the chain's next cursor
+        const bool mp = (nn & 0x40000000u) != 0u;                 // ... after a match (put(cur-2) owed)
+#ifdef SNK_STATS
+        {
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) SNK_COUNT(15);
+            if (R == 0u) SNK_COUNT(56);
+            if (R == 0u && com1) SNK_COUNT(57);
+            if (R == 0u && com2) SNK_COUNT(58);
+        }
+#endif
+        // one wave-uniform exit, decided by the chains (role 0)
+        if (__builtin_amdgcn_ballot_w64(svc & (R == 0u)) != 0ull) break;
+
+        // ---- commit ----
+        op = m ? opn : op; anchor_c = m ? ncur : anchor_c;                       // role 0's probe (the other roles' copies are not used)
+        if (com1 & ((q1 & 0x40000000u) != 0u)) { op += 3u; anchor_c = q1 & CMX; } // role 1's: token + offset, no literals
+        if (com2 & ((q2 & 0x40000000u) != 0u)) { op += 3u; anchor_c = q2 & CMX; } // role 2's
+        const bool mine = ((R == 1u) & com1) | ((R == 2u) & com2);
+        d1 = mine ? s1 : DUMMY; d2 = mine ? s2 : DUMMY; dc = c;
+        const uint32_t nc = cp + ahead;
+        const uint32_t no = nc - rbc;                                            // 0..31
+        const bool sl = no >= 16u;
+        const uint32_t lo = sl ? r1 : r0, hi = sl ? r2 : r1;
+        const uint32_t nwc = __builtin_amdgcn_alignbit(hi, lo, 2u * no);
+        const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
+        const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
+        r0 = lo; r1 = hi; rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
+        c = nc; wc = nwc; s1 = ns1; s2 = (R | (mp ? 1u : 0u)) ? ns2 : DUMMY;
+        anchor_c = R ? nc : anchor_c;
+    }
+#ifdef SNK_STATS
+    const unsigned long long stat_t1 = clock64();
+    P.loop += stat_t1 - stat_t0; P.entries++;
+#endif
+    if (R) return;
+    // role 0: hand the chain over in the state "table operations of the probe at c done, match not evaluated"
+    L.cur = vb + c; L.anchor = vb + anchor_c; L.op = op; L.step = 1u; L.nb = 63u + (c - anchor_c);
+    L.w.rb = 0x80000000u;
+    snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+#ifdef SNK_STATS
+    P.finish += clock64() - stat_t1;
+#endif
+}
 #endif
 
 // How job numbers map to ordered pairs, and how the waves of a launch share them.
@@ -1699,11 +1879,13 @@ __device__ __forceinline__ void snk_fast_lane_init(SnkFastLane &L, const SnkTabl
 // (SnkFastGrid::far_*): u32 absolute positions, 3584 B per chain, one dependent load and two fire-and-forget stores per
 // probe.  Same probe semantics, same job stream (dynamic queue), same code around the loop; the LDS waves are untouched.
 // Not for sequences with exceptions, not for the singles pass (EXC / snapshot dumps know the LDS layout only).
-template <bool ASM, bool EXC, bool FAR, bool SPEC = false>       // SPEC: chain i of the wave = the lane pair (2i, 2i+1), see snk_fast_steady_spec
+// SPEC: chain i of the wave = the lane pair (2i, 2i+1), see snk_fast_steady_spec; TRI: three lanes of a 16-lane row, see snk_fast_steady_spec3
+template <bool ASM, bool EXC, bool FAR, bool SPEC = false, uint32_t TRI = 0u>      // TRI: 0, or how far ahead role 2 probes (10 / 6)
 __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastGrid &G,
                                               uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     static_assert(!SPEC || !FAR, "two lanes per chain: the chains with their tables in LDS");
+    static_assert(!TRI || (!SPEC && !FAR && !EXC && !ASM), "three lanes per chain: the C++ statement, pure ACGT");
 #ifndef SNK_HOST_EMU
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
 #endif
@@ -1716,8 +1898,10 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
     SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
-    const uint32_t cidx = SPEC ? lane >> 1 : lane;                // the chain of the wave this lane belongs to
-    const bool lane_on = SPEC ? (!(lane & 1u) && cidx < lanes) : lane < lanes;      // ... and runs (SPEC: the odd lane only inside the steady loop)
+    // the chain of the wave this lane belongs to (TRI: rows of 16 lanes = 5 chains x 3 lanes, lane 15 idles), and its role in it
+    const uint32_t role = TRI ? ((lane & 15u) == 15u ? 3u : (lane & 15u) % 3u) : SPEC ? (lane & 1u) : 0u;
+    const uint32_t cidx = TRI ? (lane >> 4) * 5u + (lane & 15u) / 3u : SPEC ? lane >> 1 : lane;
+    const bool lane_on = role == 0u && cidx < lanes && (!TRI || (lane & 15u) != 15u);   // ... and runs (the other roles only inside the steady loop)
     // LDS waves: the chain's table at LDS address mine_off (dynamic LDS starts at 0).  FAR waves: at word far_idx * 896 of G.far_tab.
     const uint32_t mine_off = FAR ? 0u : SNK_FLUT_B + (wave * lanes + (cidx < lanes ? cidx : 0u)) * SNK_FCHAIN_B;
     uint8_t *const mine = snk_lds8 + mine_off;
@@ -1780,7 +1964,8 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 const uint32_t l = (uint32_t)__builtin_ctzll(tm);
                 const int xi  = __shfl(job.xi, (int)l);
                 const int snp = __shfl(job.snap, (int)l);
-                uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + (SPEC ? l >> 1 : l)) * SNK_FCHAIN_B;
+                const uint32_t lc = TRI ? (l >> 4) * 5u + (l & 15u) / 3u : SPEC ? l >> 1 : l;      // the chain of lane l
+                uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + lc) * SNK_FCHAIN_B;
                 const uint32_t spos = T.snap_pos[xi];
                 const bool use = (snp == 0) && (spos != 0u);
                 const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
@@ -1806,7 +1991,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                     ((uint32_t *)dst)[t] = v;
                 }
                 if (EXC) {
-                    uint32_t *ov = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + (SPEC ? l >> 1 : l)) * 4096u;
+                    uint32_t *ov = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + lc) * 4096u;
                     const uint32_t *gsrc = T.snap_gen + (size_t)xi * 4096u;
                     for (uint32_t t = lane; t < 4096u; t += SNK_COOP(64u)) ov[t] = use ? gsrc[t] : 0u;
                 }
@@ -1976,7 +2161,12 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         }
 #endif
 #ifndef SNK_HOST_EMU
-        if (SPEC) {
+        if (TRI) {
+            const uint32_t go = (have && !parked && round != 0u) ? 1u : 0u;      // (every lane of the wave is active here)
+            const uint32_t g1 = snk_row_shr1(go), g2 = snk_row_shr2(go);
+            if (role == 0u ? go != 0u : role == 1u ? g1 != 0u : role == 2u ? g2 != 0u : false)
+                snk_fast_steady_spec3<TRI ? TRI : 10u>(L, role, (snk_g8 *)T.packed_arena, tbl, bm SNK_PROF_PASS);
+        } else if (SPEC) {
             const bool go = have && !parked && waiting == 0u && round != 0u;
             const bool pgo = snk_pair_swap(go ? 1u : 0u) != 0u;                 // (every lane of the wave is active here)
             if (go || ((lane & 1u) && pgo))
@@ -2037,6 +2227,25 @@ __global__ void __launch_bounds__(512) snk_fast_spec_cxx_kernel(SnkTables T, Snk
         ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
     __syncthreads();
     snk_fast_wave<false, false, false, true>(T, G, lanes, out, status);
+}
+
+// ... three lanes per chain, C++ statement (fast_spec = 3; round 4 experiment)
+__global__ void __launch_bounds__(512) snk_fast_tri_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    snk_fast_wave<false, false, false, false, 10u>(T, G, lanes, out, status);
+}
+// ... with role 2 six bases ahead instead of ten (fast_spec = 36)
+__global__ void __launch_bounds__(512) snk_fast_tri6_cxx_kernel(SnkTables T, SnkFastGrid G, uint32_t lanes, uint32_t *out, uint32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+        ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    __syncthreads();
+    snk_fast_wave<false, false, false, false, 6u>(T, G, lanes, out, status);
 }
 
 // phase A: single sequences + prefix snapshots at upload (same code, own symbols so that profiles keep the two phases

@@ -350,7 +350,11 @@ def test_hand_scheduled_steady_loop_equals_its_cxx_statement(hip, oracle_mod):
     exp_p = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
     # (round 3) ... and both exist in two forms: two lanes per chain (fast_spec=1, the default: the second lane probes 5 bases
     # ahead in the same trip and counts when the first lane's match ends there) and one lane per chain (fast_spec=0)
-    for opts in ({}, {"fast_asm": 0}, {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0}, {"fast_lanes": 3, "fast_waves": 5}):
+    # (round 4) ... and the C++ statement with THREE lanes per chain (fast_spec=3: the third lane probes 10 bases ahead and counts
+    # when two 5-base matches follow each other; fast_spec=36: 6 bases ahead, counts when the first lane's match ends there) --
+    # built and measured negative (profiles/r04_third_lane.json), kept exact
+    for opts in ({}, {"fast_asm": 0}, {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0}, {"fast_lanes": 3, "fast_waves": 5},
+                 {"fast_spec": 3}, {"fast_spec": 36}, {"fast_spec": 3, "fast_lanes": 7, "fast_waves": 3}, {"fast_spec": 36, "fast_lanes": 4}):
         with hip.HipContext(0, **opts) as ctx:
             ctx.upload(seqs)
             assert ctx.num_packed == len(seqs)

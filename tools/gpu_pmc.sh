@@ -7,15 +7,15 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 run() {   # group name, counters...
   g=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/raw_$g" -- python3 tools/gpu_prof.py $N $L $R ${LANES:-21} ${WAVES:-4} > "$OUT/run_$g.log" 2>&1
+  rocprofv3 --pmc "$@" --kernel-include-regex "snk_fast_" --output-format csv -d "$OUT/raw_$g" -- python3 tools/gpu_prof.py $N $L $R ${LANES:-21} ${WAVES:-4} > "$OUT/run_$g.log" 2>&1
   f=$(find "$OUT/raw_$g" -name '*counter_collection.csv' | head -1)
   python3 - "$f" "$g" > "$OUT/pmc_$g.json" <<'PY'
 import csv, sys, json, collections
 tot = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    if r["Kernel_Name"].startswith("snk_fast_kernel"):
+    if r["Kernel_Name"].startswith("snk_fast_"):
         tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-print(json.dumps({"group": sys.argv[2], "kernel": "snk_fast_kernel", "per_launch": tot}))
+print(json.dumps({"group": sys.argv[2], "kernel": "snk_fast_* (pair launches of the run: a 2-row warm-up + the measured one)", "per_launch": tot}))
 PY
   cat "$OUT/pmc_$g.json"; tail -1 "$OUT/run_$g.log"; rm -rf "$OUT/raw_$g"
 }
