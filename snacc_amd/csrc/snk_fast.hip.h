@@ -1222,7 +1222,6 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #endif
 }
 
-#ifndef SNK_HOST_EMU
 // ---- the speculative loop as gfx950 code (snk_fast_steady_spec<true>) ----------------------------------------------
 // Same dataflow as the C++ statement below, scheduled like the loop above.  Differences from that statement, all exact:
 //  * role 1 reads the table with role 0 at the top; role 0's two puts of the same trip are patched into role 1's result by
@@ -1433,12 +1432,20 @@ __device__ __forceinline__ uint32_t snk_pair_swap(uint32_t v)          // the pa
 
 template <bool ASM, bool EXC>
 __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, snk_g8 *const marena,
-                                                     uint16_t *tbl, uint32_t *bm, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
+                                                     uint16_t *tbl_, uint32_t *bm_, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
 {
 #ifdef SNK_STATS
     const unsigned long long stat_te = clock64();
 #endif
+#ifdef SNK_HOST_EMU
+    // CPU emulation of the lane pair (tests/emu/): two host threads in lockstep; every LDS access of the loop is a
+    // synchronisation point of the pair, so that the accesses keep the order the wave's instructions give them
+    const uint16_t *const lut0 = (const uint16_t *)snk_lds8;
+    SnkEmuLds<uint16_t> tbl(tbl_); SnkEmuLds<uint32_t> bm(bm_);
+#else
+    uint16_t *const tbl = tbl_; uint32_t *const bm = bm_;
     const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
+#endif
     // role 1 takes the chain's state at the loop entry from role 0
     uint32_t vb = L.base, lx = L.s.lx, xoff = L.s.xoff, yoff = L.s.yoff, mfl1 = L.mfl1, olimit = L.olimit;
     uint32_t cur0 = L.cur, anchor0 = L.anchor, op = L.op, pend0 = L.pending ? 1u : 0u, wrb = L.w.rb, wsoff = L.w.soff, worg = L.w.org;
@@ -1482,6 +1489,7 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     const unsigned long long stat_t0 = clock64();
     P.prologue += stat_t0 - stat_te;
 #endif
+#ifndef SNK_HOST_EMU
     if (ASM) {
         const uint64_t r1m = __builtin_amdgcn_ballot_w64(R1);                   // role 1 among the lanes in the loop
         const uint32_t five = R1 ? 5u : 0u;
@@ -1525,6 +1533,7 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
 #endif
         return;
     }
+#endif
     for (;;) {
         // ---- table, in liblz4's order for the chain: role 1's probe of the last trip (put, put), then role 0's (put, get, put);
         //      role 1 only reads at its new cursor.  A lane that has nothing to write writes the unused slot.
@@ -1627,6 +1636,7 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     else     snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
 }
 
+#ifndef SNK_HOST_EMU
 // ---- three lanes per chain (round 4; C++ statement, option fast_spec = 3) -------------------------------------------------
 // Rows of 16 lanes hold 5 chains x 3 lanes (lane 15 of every row idles: 20 chains per wave): role 0 is the chain, role 1
 // probes 5 bases ahead as in snk_fast_steady_spec, role 2 TEN bases ahead -- where the chain stands when two 5-base matches
@@ -2160,7 +2170,15 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
             }
         }
 #endif
-#ifndef SNK_HOST_EMU
+#ifdef SNK_HOST_EMU
+        if (SPEC) {     // the emulated lane is role 0 of its pair; its partner lives for the duration of the loop (snk_host_emu.h)
+            if (have && !parked && waiting == 0u && round != 0u)
+                snk_emu_pair_run([&](bool r1, SnkFastLane &Lr) {
+                    snk_fast_steady_spec<false, EXC>(Lr, r1, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena),
+                                                     tbl, bm, mine_off, round SNK_PROF_PASS);
+                }, L);
+        } else
+#else
         if (TRI) {
             const uint32_t go = (have && !parked && round != 0u) ? 1u : 0u;      // (every lane of the wave is active here)
             const uint32_t g1 = snk_row_shr1(go), g2 = snk_row_shr2(go);

@@ -24,8 +24,18 @@ bool acgt(uint8_t c) { return c == ('A' | g_lcase) || c == ('C' | g_lcase) || c 
 // the 2-bit kernel (0: pure ACGT only).  Entries of `singles` / `pairs` that the kernel does not serve stay 0.
 // far != 0: the pairs run as a FAR chain (table in "global" memory: u32 absolute positions, snk_fast_wave<.., FAR = true>)
 // -- only for sets without exceptions (as the launch code decides).
+// spec != 0: two lanes per chain (snk_fast_wave<.., SPEC = true>, what every product launch of the 2-bit kernel runs): the
+// emulated lane is role 0 of its pair, the partner runs on a second host thread inside the steady loop (snk_host_emu.h).
+template <bool EXC> static void emu_launch(const SnkTables &T, const SnkFastGrid &G, uint32_t *out, uint32_t *status, bool spec)
+{
+    if (!spec) { snk_fast_kernel_body<false, EXC>(T, G, 1u, out, status); return; }
+    for (uint32_t t = 0; t < 512u; ++t) ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    snk_fast_wave<false, EXC, false, true>(T, G, 1u, out, status);
+}
+
 extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t *lens,
-                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit, uint32_t lower, uint32_t far)
+                              uint32_t *singles, uint32_t *pairs, uint32_t header_bytes, uint32_t exc_limit, uint32_t lower, uint32_t far,
+                              uint32_t spec)
 {
     g_lcase = lower ? 0x20 : 0;
     const char code2byte[4] = { (char)('A' | g_lcase), (char)('C' | g_lcase), (char)('T' | g_lcase), (char)('G' | g_lcase) };
@@ -130,8 +140,8 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
         SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
         SnkFastGrid G; G.jobs = &jb; G.n_jobs = 1u; G.r0 = 0u; G.rows = 1u; G.n = 1u; G.batch = 1u; G.queue = nullptr; G.yorder = nullptr;
-        if (any_exc) snk_fast_kernel_body<false, true>(T, G, 1u, singles, status.data());
-        else         snk_fast_kernel_body<false, false>(T, G, 1u, singles, status.data());
+        if (any_exc) emu_launch<true>(T, G, singles, status.data(), spec != 0);
+        else         emu_launch<false>(T, G, singles, status.data(), spec != 0);
     }
     // all eligible pairs as ONE launch of one lane: the lane walks the job list through the kernel's own
     // hand-out loop (a finished lane takes the next job), alternately as an explicit list and, when every
@@ -155,8 +165,9 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         else                              { G.jobs = list.data(); G.n_jobs = (uint32_t)list.size(); }
         std::vector<uint32_t> far_tab(SNK_FSLOTS, 0xDEADBEEFu);
         if (far && !any_exc) { G.far_tab = far_tab.data(); G.lds_waves = 0u; G.far_lanes = 1u; G.far_stop = 0u; G.queue = &counter; }
-        if (any_exc) snk_fast_kernel_body<false, true>(T, G, 1u, pairs, status.data());
-        else         snk_fast_kernel_body<false, false>(T, G, 1u, pairs, status.data());
+        if (any_exc)                   emu_launch<true>(T, G, pairs, status.data(), spec != 0);
+        else if (far)                  snk_fast_kernel_body<false, false>(T, G, 1u, pairs, status.data());
+        else                           emu_launch<false>(T, G, pairs, status.data(), spec != 0);
     }
     return (int)status[0];
 }

@@ -1,5 +1,6 @@
 """The 2-bit kernel's own source (snacc_amd/csrc/snk_fast.hip.h), compiled for the host and run one
-lane at a time (tests/emu/), against the oracle: the parse logic is checked here without a GPU; the
+lane at a time (tests/emu/) -- and, for the two-lane steady loop every product launch runs, as a lane PAIR on
+two host threads in lockstep -- against the oracle: the parse logic is checked here without a GPU; the
 `-m gpu` suite then checks the same code as 64-lane waves on the card."""
 import numpy as np
 import pytest
@@ -38,6 +39,11 @@ def check(seqs, exc_limit=128):
     es, ep = expect(seqs, exc_limit)
     assert np.array_equal(s, es), (s, es)
     assert np.array_equal(p, ep), np.argwhere(p != ep)[:8].tolist()
+    # (round 4) the same set through the loop every product launch runs: TWO lanes per chain (snk_fast_steady_spec's C++
+    # statement), the emulated lane's partner on a second host thread in lockstep -- with and without exceptions
+    s2, p2 = fast_sizes(seqs, exc_limit=exc_limit, spec=True)
+    assert np.array_equal(s2, es), ("two lanes", s2, es)
+    assert np.array_equal(p2, ep), ("two lanes", np.argwhere(p2 != ep)[:8].tolist())
     if all(_packable(x, 0) or len(x) == 0 for x in seqs):
         # pure ACGT sets: the same pairs again as a FAR chain (table in global memory, u32 absolute positions)
         _, pf = fast_sizes(seqs, exc_limit=exc_limit, far=True)
@@ -223,8 +229,49 @@ def test_emu_lower_case_set():
     seqs[1][40000:40700] &= 0xDF                        # an upper-case stretch
     seqs[3][70000:70060] = ord("n")
     seqs[3][131000:131200] &= 0xDF
-    s, p = fast_sizes(seqs, exc_limit=65536, lower=True)
     es = np.array([o.lz4f_size(x) for x in seqs], dtype=np.uint32)
     ep = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
-    assert np.array_equal(s, es), (s, es)
-    assert np.array_equal(p, ep), np.argwhere(p != ep)[:8].tolist()
+    for spec in (False, True):
+        s, p = fast_sizes(seqs, exc_limit=65536, lower=True, spec=spec)
+        assert np.array_equal(s, es), (spec, s, es)
+        assert np.array_equal(p, ep), (spec, np.argwhere(p != ep)[:8].tolist())
+
+
+def test_emu_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The kernel's source as g++ compiles it for the emulation, built with -fsanitize=address,undefined (no recovery) and run in
+    a child interpreter with the ASan runtime preloaded: pure ragged sets, N runs / IUPAC codes, soft-masked stretches -- each
+    as one lane and as the lane pair of the two-lane loop.  A sanitizer report ends the child with a non-zero status."""
+    import os
+    import subprocess
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no ASan runtime for this gcc")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "snacc_amd", "csrc")
+    so = str(tmp_path / "libfast_emu_san.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-Wno-unused-function", "-DSNK_HOST_EMU", "-I", here, "-I", csrc,
+                           "-shared", "-fPIC", "-pthread", "-o", so, os.path.join(here, "fast_emu.cpp")])
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(here))!r})
+import numpy as np
+import oracle, emu
+import test_kernel_emu as t
+emu._SO = {so!r}
+emu.build = lambda: emu._SO
+rng = np.random.default_rng(77)
+t.check([oracle.lcg_genome(11 + k, n) for k, n in enumerate([65536, 65537, 131072, 30000, 12, 65535 + 65536, 100003])])
+g = [oracle.lcg_genome(200 + k, n) for k, n in enumerate([150000, 90001, 70000])]
+ex = [t._with_exceptions(rng, g[0], 2, 3), g[1], t._with_exceptions(rng, g[2], 1, 4)]
+ex[2][:40] = ord("N"); ex[0][65530:65545] = ord("N")
+t.check(ex, exc_limit=4096)
+sm = [t._soft_masked(rng, g[0], 5), g[1], t._soft_masked(rng, g[2], 20, 300)]
+sm[2][-400:] |= 0x20
+t.check(sm, exc_limit=65536)
+print("sanitized emulation ok")
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0 and "sanitized emulation ok" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
