@@ -1,97 +1,9 @@
 """Randomised GPU stress: random sequence sets (lengths, alphabets, repeats), ALL pairs and singles
-through every kernel family, compared with the oracle.  Usage: gpu_fuzz.py SEED0 NSEEDS"""
+through every kernel family and loop form (tests/fuzzgen_lz4.py), compared with the oracle.  Usage: gpu_fuzz.py SEED0 NSEEDS"""
 import sys, time
 sys.path.insert(0, '.')
-import numpy as np
-import oracle
-from oracle.loader import pairs_mt
-from snacc_amd import hip_backend as hip
-
-ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
-BSPEC_DEFAULT = 0      # the library's default of "bytes_spec" (the fuzz runs the other setting as extra configurations)
-
-
-def gen(rng, n, kind):
-    if n == 0:
-        return np.zeros(0, np.uint8)
-    if kind == "acgt":
-        return rng.choice(ACGT, n)
-    if kind == "acgtn":
-        a = rng.choice(ACGT, n)
-        for _ in range(int(rng.integers(1, 6))):
-            s = int(rng.integers(0, n)); a[s:s + int(rng.integers(1, 400))] = ord("N")
-        return a
-    if kind == "soft":
-        a = rng.choice(ACGT, n)
-        for _ in range(int(rng.integers(1, 6))):
-            s = int(rng.integers(0, n)); e = s + int(rng.integers(1, 3000)); a[s:e] |= 0x20
-        return a
-    if kind == "bytes":
-        return rng.integers(0, 256, n, dtype=np.uint8)
-    if kind == "aa":
-        return rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8), n)
-    if kind == "repeat":
-        unit = rng.choice(ACGT, int(rng.integers(1, 3000)))
-        a = np.tile(unit, n // len(unit) + 1)[:n].copy()
-        m = rng.random(n) < rng.choice([0.0, 0.001, 0.02])
-        a[m] = rng.choice(ACGT, int(m.sum()))
-        return a
-    if kind == "mix":
-        parts, tot = [], 0
-        while tot < n:
-            k = str(rng.choice(["acgt", "acgtn", "bytes", "repeat", "soft"]))
-            ln = int(rng.integers(1, 90000)); parts.append(gen(rng, ln, k)); tot += ln
-        return np.concatenate(parts)[:n]
-    raise ValueError(kind)
-
-
-def rand_len(rng):
-    c = rng.integers(0, 6)
-    if c == 0: return int(rng.integers(0, 40))
-    if c == 1: return int(rng.integers(40, 33000))
-    if c == 2: return int(65536 * rng.integers(1, 4) + rng.integers(-20, 21))
-    if c == 3: return int(rng.integers(60000, 70000))
-    return int(rng.integers(65537, 260000))
-
-
-def one(seed):
-    rng = np.random.default_rng(seed)
-    profile = str(rng.choice(["pure", "withN", "soft", "anything"]))
-    kinds = {"pure": ["acgt", "repeat"], "withN": ["acgt", "acgtn", "repeat"], "soft": ["acgt", "soft", "acgtn"],
-             "anything": ["acgt", "acgtn", "soft", "bytes", "aa", "repeat", "mix"]}[profile]
-    n = int(rng.integers(6, 15))
-    seqs = [gen(rng, rand_len(rng), str(rng.choice(kinds))) for _ in range(n)]
-    # relatives: mutated / shifted / truncated copies of earlier members (long cross-seam matches)
-    for _ in range(int(rng.integers(0, 4))):
-        src = seqs[int(rng.integers(0, len(seqs)))]
-        if len(src) < 100:
-            continue
-        a = src.copy()
-        hit = rng.random(len(a)) < rng.choice([0.0, 0.0005, 0.01, 0.1])
-        a[hit] = rng.choice(ACGT, int(hit.sum()))
-        for _ in range(int(rng.integers(0, 4))):                    # indels
-            q = int(rng.integers(0, len(a)))
-            a = np.concatenate([a[:q], rng.choice(ACGT, int(rng.integers(0, 50))), a[q + int(rng.integers(0, 50)):]])
-        s0 = int(rng.integers(0, min(len(a) // 2, 70000) + 1))
-        seqs[int(rng.integers(0, len(seqs)))] = a[s0:]
-    n = len(seqs)
-    exp_s = np.array([oracle.lz4f_size(x) for x in seqs], dtype=np.uint32)
-    exp_p = pairs_mt(seqs, 0, n, 16)
-    bad = []
-    for opts in ({}, {"fast_asm": 0}, {"force_generic": 1}, {"bytes_compact": 0}, {"force_generic": 1, "bytes_legacy": 1},
-                 {"fast_lanes": 5, "fast_waves": 3, "cbytes_lanes": 4, "cbytes_waves": 2},
-                 {"force_generic": 1, "bytes_gt": 2}, {"force_generic": 1, "bytes_compact": 0, "bytes_gt": 3},      # tables in global memory
-                 {"force_generic": 1, "bytes_spec": 1 - BSPEC_DEFAULT}, {"force_generic": 1, "bytes_compact": 0, "bytes_gt": 0, "bytes_spec": 1 - BSPEC_DEFAULT},   # byte kernels, the other number of lanes per chain
-                 {"force_generic": 1, "bytes_spec": 1 - BSPEC_DEFAULT, "cbytes_lanes": 3, "cbytes_waves": 2},
-                 {"exc_limit": 16384}, {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0}):            # ... one lane per chain (the default has two)                                                                             # dense exceptions stay on the 2-bit kernel
-        with hip.HipContext(0, **opts) as ctx:
-            ctx.upload(seqs)
-            s, p = ctx.singles(), ctx.pairs()
-            info = (ctx.num_packed, ctx.num_compact_hashes)
-        if not (np.array_equal(s, exp_s) and np.array_equal(p, exp_p)):
-            bad.append((opts, np.argwhere(p != exp_p)[:4].tolist(), np.argwhere(s != exp_s)[:4].tolist()))
-    return profile, n, [len(x) for x in seqs], info, bad
-
+sys.path.insert(0, 'tests')
+from fuzzgen_lz4 import one
 
 seed0, nseeds = int(sys.argv[1]), int(sys.argv[2])
 fails = 0
