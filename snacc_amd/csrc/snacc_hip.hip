@@ -78,6 +78,7 @@ struct snk_ctx_impl {
     std::vector<uint8_t> is_packed;  // goes to the 2-bit kernel: pure ACGT, or ACGT with a few exceptions
     std::vector<uint8_t> has_exc;    // ... the latter
     bool any_exc = false;
+    bool any_other = false;          // ... and some exception byte of a 2-bit sequence is a letter of the other case (soft-masked stretches)
     bool lower = false;              // the resident set's letters are acgt: its 2-bit sequences, LUTs and exceptions go by the lower case
     long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (25 % of
                                      // them at 2048) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload); beyond that the
@@ -85,6 +86,8 @@ struct snk_ctx_impl {
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
     uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr, *d_lut_okey = nullptr;
+    uint16_t *d_lut_oj = nullptr; uint32_t *d_lut_omap = nullptr;     // the other-case mode's compact slots (snk_oth_swap_in)
+    uint32_t *d_osave = nullptr;                                      // ... and its save areas, one per resident chain (beside d_ovf)
     // deflate add-on (snk_deflate.hip): opaque state + its destructor
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
     bool dfl_serial = false, dfl_kmer = true, dfl_norestart = false;
@@ -231,11 +234,11 @@ void free_sequences(snk_ctx_impl *c)
 {
     dfree(c->d_bytes); dfree(c->d_packed); dfree(c->d_pmask); dfree(c->d_slots); dfree(c->d_bytes_ptr); dfree(c->d_packed_off); dfree(c->d_bytes_off);
     dfree(c->d_len); dfree(c->d_snap_pos); dfree(c->d_snap_out); dfree(c->d_snap_fast); dfree(c->d_yorder);
-    dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); c->ovf_bytes = 0; c->ovf_in_flight = false;
+    dfree(c->d_snap_gen); dfree(c->d_single); dfree(c->d_exc_flags); dfree(c->d_exc_off); dfree(c->d_ovf); dfree(c->d_osave); c->ovf_bytes = 0; c->ovf_in_flight = false;
     dfree(c->d_exc_runs); dfree(c->d_exc_roff);
     dfree(c->d_far); c->far_bytes = 0; c->far_in_flight = false;
     dfree(c->d_bgt); c->bgt_bytes = 0; c->bgt_in_flight = false;
-    c->has_exc.clear(); c->any_exc = false;
+    c->has_exc.clear(); c->any_exc = false; c->any_other = false;
     c->n = 0; c->n_packed = 0; c->len.clear(); c->boff.clear(); c->is_packed.clear(); c->singles_done = false; c->single_have.clear();
     if (c->dfl && c->dfl_free) c->dfl_free(c->dfl);
     c->dfl = nullptr;
@@ -282,6 +285,11 @@ int upload_luts(snk_ctx_impl *c)
         std::vector<uint16_t> okey(1024);
         for (uint32_t k = 0; k < 1024; ++k) okey[k] = h2s[ohash[k]] != 0xFFFF ? h2s[ohash[k]] : (uint16_t)(0x1000u | ohash[k]);
         HIPCHK(c, hipMemcpy(c->d_lut_okey, okey.data(), 2048, hipMemcpyHostToDevice));
+        // the other case's own numbering (the other-case mode keeps its table in LDS): oslot is code -> compact slot already
+        std::vector<uint32_t> omap(SNK_FSLOTS, 0xFFFF0000u);
+        for (uint32_t k = 0; k < 1024; ++k) omap[oslot[k]] = ohash[k] | ((uint32_t)h2s[ohash[k]] << 16);
+        HIPCHK(c, hipMemcpy(c->d_lut_oj, oslot.data(), 2048, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_lut_omap, omap.data(), SNK_FSLOTS * 4, hipMemcpyHostToDevice));
     }
     HIPCHK(c, hipMemcpy(c->d_lut_h2s, h2s.data(), 8192, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_lut_s2h, s2h.data(), SNK_FSLOTS * 2, hipMemcpyHostToDevice));
@@ -298,6 +306,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
     T.exc_runs = c->d_exc_runs; T.exc_roff = c->d_exc_roff;
     T.exc_flags = c->d_exc_flags; T.exc_off = c->d_exc_off; T.lut_h2s = c->d_lut_h2s; T.lut_s2h = c->d_lut_s2h; T.lut_okey = c->d_lut_okey; T.ovf = c->d_ovf;
+    T.lut_oj = c->d_lut_oj; T.lut_omap = c->d_lut_omap; T.osave = c->d_osave;
     T.slots = c->d_slots; T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
@@ -318,17 +327,26 @@ int ensure_scratch(snk_ctx_impl *c, size_t n_jobs, size_t n_out)
 }
 
 // Chains per wave of a 2-bit kernel workgroup under the current options (fast_lanes = 0: as many as the LDS holds).
-int fast_geometry(snk_ctx_impl *c, uint32_t *lanes_out)
+int fast_geometry(snk_ctx_impl *c, uint32_t *lanes_out, uint32_t *short_last = nullptr)
 {
     const uint32_t waves = (uint32_t)c->fast_waves;
     uint32_t lanes = (uint32_t)c->fast_lanes;
+    // (a resident set with letters of the other case -- soft-masked stretches -- runs with the other case's LUT in LDS too: 2 KiB
+    // fewer for the chains, 83 instead of 84: the last wave of a workgroup then runs one chain fewer, `short_last`)
+    const size_t lut_b = c->any_other ? 2u * (size_t)SNK_FLUT_B : (size_t)SNK_FLUT_B;
+    uint32_t shortl = 0u;
     if (lanes == 0u) {
-        lanes = (uint32_t)((160 * 1024 - SNK_FLUT_B) / ((size_t)waves * SNK_FCHAIN_B));
+        lanes = (uint32_t)((160 * 1024 - (size_t)SNK_FLUT_B) / ((size_t)waves * SNK_FCHAIN_B));
         if (lanes > 64u) lanes = 64u;
+        if (lut_b + (size_t)lanes * waves * SNK_FCHAIN_B > 160 * 1024) {
+            if (lanes > 1u && lut_b + ((size_t)lanes * waves - 1u) * SNK_FCHAIN_B <= 160 * 1024) shortl = 1u;
+            else lanes = (uint32_t)((160 * 1024 - lut_b) / ((size_t)waves * SNK_FCHAIN_B));
+        }
     }
-    if (lanes == 0u || SNK_FLUT_B + (size_t)lanes * waves * SNK_FCHAIN_B > 160 * 1024)
-        return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max 84)", lanes * waves);
+    if (lanes == 0u || lut_b + ((size_t)lanes * waves - shortl) * SNK_FCHAIN_B > 160 * 1024)
+        return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max %d)", lanes * waves, c->any_other ? 83 : 84);
     *lanes_out = lanes;
+    if (short_last) *short_last = shortl;
     return SNK_OK;
 }
 
@@ -343,9 +361,10 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     if (n_fast) {
         uint32_t waves = (uint32_t)c->fast_waves;
         const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
-        uint32_t lanes = 0;
-        if (fast_geometry(c, &lanes) != SNK_OK) return SNK_E_ARG;
+        uint32_t lanes = 0, short_last = 0;
+        if (fast_geometry(c, &lanes, &short_last) != SNK_OK) return SNK_E_ARG;
         if (singles && c->fast_lanes == 0) {
+            short_last = 0u;
             // Phase A has N jobs, not N^2, and no two of them share a byte: what counts is one chain's serial parse.  Measured
             // (tools/gpu_singles.py, tools/gpu_geom.py, 1024 x 1 Mbp): 84-chain workgroups on 13 CUs 85 ms (one lane per chain) /
             // 62 ms (two); spread over all CUs as 4 waves x 1 chain 92 ms -- waves with fewer than ~8 chains slow each other
@@ -360,8 +379,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         const bool tri = (c->fast_spec == 3 || c->fast_spec == 36) && !exc && !singles && c->far_lanes == 0;     // three lanes per chain: 5 chains per 16-lane row
         if (tri && lanes > 20u) lanes = 20u;
         const uint32_t chains = lanes * waves;
-        const size_t lds = (size_t)SNK_FLUT_B + (size_t)chains * SNK_FCHAIN_B;
+        const size_t lds = (c->any_other ? 2u : 1u) * (size_t)SNK_FLUT_B + (size_t)(chains - short_last) * SNK_FCHAIN_B;
         SnkFastGrid G;
+        G.short_last = short_last; G.flut = (c->any_other ? 2u : 1u) * SNK_FLUT_B;
         const bool dense = tile && tile->rows > 0;
         // far chains (tables in global memory, extra waves): pair launches of pure-ACGT sets that fill the card
         uint32_t far_waves = (!exc && !singles && c->far_lanes > 0) ? (uint32_t)c->far_waves : 0u;
@@ -414,10 +434,11 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             if (need > c->ovf_bytes) {
                 HIPCHK(c, hipStreamSynchronize(st));
                 if (c->ovf_in_flight) { HIPCHK(c, hipEventSynchronize(c->ovf_busy)); c->ovf_in_flight = false; }
-                dfree(c->d_ovf);
+                dfree(c->d_ovf); dfree(c->d_osave);
                 HIPCHK(c, hipMalloc((void **)&c->d_ovf, need));
+                HIPCHK(c, hipMalloc((void **)&c->d_osave, need / 8u));      // 2 KiB per chain: its set-case table while the other case's is in LDS
                 c->ovf_bytes = need;
-                T.ovf = c->d_ovf;
+                T.ovf = c->d_ovf; T.osave = c->d_osave;
             }
         }
         // (launches with exceptions share the context's overflow tables: one at a time, whatever their streams)
@@ -761,6 +782,8 @@ int snk_ctx_create(int device, snk_ctx **out)
         CRCHK(hipMalloc((void **)&c->d_lut_h2s, 4096 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_s2h, SNK_FSLOTS * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_okey, 1024 * sizeof(uint16_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_oj, 1024 * sizeof(uint16_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_omap, SNK_FSLOTS * sizeof(uint32_t)));
         if (upload_luts(c) != SNK_OK) { snk_ctx_destroy(c); return SNK_E_STATE; }
     }
 #undef CRCHK
@@ -774,7 +797,7 @@ void snk_ctx_destroy(snk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_sequences(c);
-    dfree(c->d_lut_h2s); dfree(c->d_lut_s2h); dfree(c->d_lut_okey);
+    dfree(c->d_lut_h2s); dfree(c->d_lut_s2h); dfree(c->d_lut_okey); dfree(c->d_lut_oj); dfree(c->d_lut_omap);
     dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_lut_h2c4); dfree(c->d_hashset); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
     for (auto &e : c->ev_log) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -886,9 +909,9 @@ int snk_num_packed(const snk_ctx *c) { return c ? c->n_packed : SNK_E_ARG; }
 int snk_fast_chains(snk_ctx *c)
 {
     if (!c) return SNK_E_ARG;
-    uint32_t lanes = 0;
-    if (fast_geometry(c, &lanes) != SNK_OK) return SNK_E_ARG;
-    return (int)(lanes * (uint32_t)c->fast_waves);
+    uint32_t lanes = 0, short_last = 0;
+    if (fast_geometry(c, &lanes, &short_last) != SNK_OK) return SNK_E_ARG;
+    return (int)(lanes * (uint32_t)c->fast_waves - short_last);
 }
 int snk_lengths(const snk_ctx *c, uint64_t *lens)
 {
@@ -1020,7 +1043,7 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     // (a third / 45 % of the bases after the stretches' overlap) the 2-bit kernel still runs at 11 / 9 %.  So a sequence
     // stays on it up to 60 % of its 16-base granules flagged and 4 + 6144 sites per 2^20 bases; the case with fewer
     // letters is the flagged one (see the sample above).
-    c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false;
+    c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false; c->any_other = false;
     std::vector<uint32_t> eoff(n, 0xFFFFFFFFu), runs, roff(n, 0);
     {
         std::vector<uint32_t> raw_all;                      // the raw granule flags of every sequence: ONE copy, when a candidate has any
@@ -1038,6 +1061,7 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
             if (!c->is_packed[g] || ecount[g] == 0) continue;
             const uint32_t *raw = raw_all.data() + foff[g];
             const size_t first = runs.size();
+            bool other = false;                                        // a letter of the other case among this sequence's exceptions
             for (size_t w = 0; w < fwords[g]; ++w) {
                 uint32_t bits = raw[w];
                 while (bits) {
@@ -1046,6 +1070,7 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
                     for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
                         const uint8_t ch = seqs[g][i];
                         if (ch == ('A' | lcase) || ch == ('C' | lcase) || ch == ('G' | lcase) || ch == ('T' | lcase)) continue;
+                        { const uint8_t u = (uint8_t)(ch & ~0x20u); other |= (u == 'A' || u == 'C' || u == 'G' || u == 'T'); }
                         if (runs.size() > first && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;       // extends the open run
                         else { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); }
                     }
@@ -1060,6 +1085,7 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
             roff[g] = (uint32_t)(first / 2);
             runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
             c->has_exc[g] = 1; c->any_exc = true; eoff[g] = foff[g];
+            c->any_other |= other;
         }
     }
     c->up_ms[1] = up_lap();

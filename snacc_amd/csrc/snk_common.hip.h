@@ -88,6 +88,12 @@ struct SnkTables {
     const uint16_t *lut_okey;         // [1024] 5-mer code -> where liblz4 keeps the 5-mer written in the OTHER case: the slot of the
                                       // 2-bit table (< 896) when a 5-mer of the set's case has the same hash, else 0x1000 | hash (ovf)
     uint32_t       *ovf;              // [resident chains][4096] overflow tables (absolute positions, liblz4's own layout)
+    // the other-case mode on a table in LDS (round 4, snk_oth_swap_in / _out): the liblz4 hashes of the 1024 other-case 5-mers
+    // numbered 0 .. 894 ("compact other-case slots")
+    const uint16_t *lut_oj;           // [1024] 5-mer code -> compact other-case slot (the kernels keep a copy at LDS offset 2048)
+    const uint32_t *lut_omap;         // [896]  compact other-case slot -> liblz4 hash | (slot of the 2-bit table when a 5-mer of the
+                                      //        set's case has the same hash, else 0xFFFF) << 16; entry 895 unused
+    uint32_t       *osave;            // [resident chains][512] where a chain's set-case table waits while its LDS region holds the other case's
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };
 

@@ -136,7 +136,7 @@ __device__ unsigned long long snk_stats[64];      // [32..63]: the same account 
 #endif
 // the cycle account is kept in registers and added to snk_stats once, when the wave ends (atomics on the way would
 // change what they measure): every lane carries the same numbers, lane 0 reports them
-struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top, other, otrips, olanes; unsigned int entries, rounds, jobs, oruns; };
+struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top, other, otrips, olanes, oin, oout; unsigned int entries, rounds, jobs, oruns, oswaps; };
 #define SNK_PROF_ARG , SnkProf &P
 #define SNK_PROF_PASS , P
 #else
@@ -425,6 +425,148 @@ __device__ __forceinline__ bool snk_exc_other_ready(SnkFastLane &L)
     L.olo = cur;
     L.olim = org + (bad != 0xFFFFFFFFu ? bad : q) - 11u;                    // first cursor whose window reaches the bad base
     return L.olim > cur;
+}
+
+
+// ---- the other-case table of a chain in its LDS region, for the length of a stretch (round 4) ------------------------------
+// Inside a stretch of the other case every probe keys on an other-case 5-mer: 1024 codes, 895 (894) distinct liblz4 hashes,
+// numbered 0 .. 894 by T.lut_oj.  About a quarter of those hashes are also hashes of set-case 5-mers (their entries live in the
+// chain's 2-bit table), the others live in the chain's overflow table in global memory -- where round 3's other-case mode read
+// and wrote them once per probe: four dependent global accesses per trip, 159 GB of HBM traffic per launch at 5 % lower case
+// (profiles/r04_pmc_traffic_softmask5.json).  Here the lanes gathered at a stretch swap tables instead: the set-case table
+// goes out to the chain's save area (raw copy), the other-case entries come in -- shared ones from the table itself, the
+// others from the overflow table, converted to the table's (16-bit offset, written-this-block bit) form, which states liblz4's
+// distance rule exactly as for every other entry -- the stretch is walked by the hand-scheduled loop on a table of the usual
+// layout with the other case's LUT, and at the end everything goes back where the general path expects it.  No block edge is
+// crossed inside the mode (the loop's limit includes the block's), so the conversions use one base.
+// All lanes of the wave work on one chain at a time (`lane`: 0 .. 63; the CPU emulation's one lane walks the loops alone).
+#define SNK_OTH_SLOTS 895u
+// (What the swaps cost decides whether the mode pays: the first form -- one chain at a time, the map and the overflow entries
+// loaded inside the per-chain loops -- took 312 k + 264 k cycles per stretch and wave, six dependent global latencies per chain.
+// Here the map is read once per swap, and the overflow-table loads / save-area loads of the NEXT chain are in flight while the
+// current chain is converted.)
+struct SnkOthChain { uint8_t *region; uint32_t *ov; uint32_t *sv; uint32_t base; };
+#define SNK_OTH_STR  SNK_COOP(64u)
+#define SNK_OTH_NPL  ((SNK_FSLOTS + SNK_OTH_STR - 1u) / SNK_OTH_STR)            /* entries per lane: 14 (the emulation's one lane: 896) */
+#define SNK_OTH_NSV  ((SNK_FCHAIN_B / 4u + SNK_OTH_STR - 1u) / SNK_OTH_STR)     /* words of a table per lane: 8 */
+
+// the chain of lane l of the wave (wave-uniform description, every lane gets the same)
+template <bool SPEC>
+__device__ __forceinline__ SnkOthChain snk_oth_chain(const SnkTables &T, uint8_t *lds, uint32_t l, uint32_t flut, uint32_t wave, uint32_t lanes,
+                                                     size_t chain0, uint32_t base_of_lane)
+{
+    const uint32_t lc = SPEC ? l >> 1 : l;
+    SnkOthChain c;
+    c.region = lds + flut + (size_t)(wave * lanes + lc) * SNK_FCHAIN_B;
+    c.ov = T.ovf + (chain0 + lc) * 4096u;
+    c.sv = T.osave + (chain0 + lc) * 512u;
+    c.base = (uint32_t)__shfl((int)base_of_lane, (int)l);
+    return c;
+}
+
+template <bool SPEC>
+__device__ __forceinline__ void snk_oth_swap_in_all(const SnkTables &T, uint8_t *lds, unsigned long long tm, uint32_t flut, uint32_t wave, uint32_t lanes,
+                                                    size_t chain0, uint32_t my_base, uint32_t lane)
+{
+    uint32_t om[SNK_OTH_NPL];                                  // this lane's entries of the map: hash | shared slot << 16
+#pragma unroll
+    for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) {
+        const uint32_t j = lane + SNK_OTH_STR * i;
+        om[i] = j < SNK_OTH_SLOTS ? T.lut_omap[j] : 0u;
+    }
+    // (1) every set-case table out (raw copies; nothing waits for them)
+    for (unsigned long long t2 = tm; t2; t2 &= t2 - 1ull) {
+        const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(t2), flut, wave, lanes, chain0, my_base);
+        const uint32_t *r32 = (const uint32_t *)c.region;
+        for (uint32_t t = lane; t < SNK_FCHAIN_B / 4u; t += SNK_OTH_STR) c.sv[t] = r32[t];
+    }
+    // (2) the other-case entries in: shared slots from the table itself, the others from the overflow table.  pc[i] holds the
+    // overflow entry of THIS chain until it is converted and is then given the load of the NEXT chain's, which is in flight
+    // while this chain's table is written (one register set: the kernel must not spill)
+    uint32_t pc[SNK_OTH_NPL];
+    {
+        const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(tm), flut, wave, lanes, chain0, my_base);
+#pragma unroll
+        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) pc[i] = c.ov[om[i] & 0xFFFu];
+    }
+    for (unsigned long long t2 = tm; t2; t2 &= t2 - 1ull) {
+        const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(t2), flut, wave, lanes, chain0, my_base);
+        const unsigned long long t3 = t2 & (t2 - 1ull);
+        const SnkOthChain n = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(t3 ? t3 : t2), flut, wave, lanes, chain0, my_base);
+        uint16_t *const tb = (uint16_t *)c.region;
+        uint32_t *const bmw = (uint32_t *)(c.region + SNK_FSLOTS * 2u);
+        uint32_t val[SNK_OTH_NPL];                             // offset | bit << 16
+        // (branch-free: both sources are read for every entry -- a shared slot's index is a valid index of the overflow table and the
+        // other way round --, the map decides by a select; the loads of the next chain go out as soon as this chain's are used)
+#pragma unroll
+        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) {
+            const uint32_t j = lane + SNK_OTH_STR * i, sl = om[i] >> 16, sx = sl < SNK_FSLOTS ? sl : 0u;
+            const uint32_t vs = tb[sx] | (((bmw[sx >> 5] >> (sx & 31u)) & 1u) << 16);
+            const int32_t rel = (int32_t)(pc[i] - c.base);                             // absolute position -> the table's form
+            const uint32_t vo = rel >= 0 ? ((uint32_t)rel | 0x10000u) : rel >= -65536 ? (uint32_t)(rel + 65536) : 0u;
+            pc[i] = n.ov[om[i] & 0xFFFu];                                              // the next chain's entry (the last chain: its own again)
+            val[i] = j < SNK_OTH_SLOTS ? (sl != 0xFFFFu ? vs : vo) : 0u;
+        }
+        for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_OTH_STR) bmw[t] = 0u;      // (after every read of the old table)
+#pragma unroll
+        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) {
+            const uint32_t j = lane + SNK_OTH_STR * i;
+            if (j < SNK_FSLOTS) {
+                tb[j] = (uint16_t)val[i];
+                if (val[i] >> 16) atomicOr(&bmw[j >> 5], 1u << (j & 31u));
+            }
+        }
+    }
+}
+
+template <bool SPEC>
+__device__ __forceinline__ void snk_oth_swap_out_all(const SnkTables &T, uint8_t *lds, unsigned long long tm, uint32_t flut, uint32_t wave, uint32_t lanes,
+                                                     size_t chain0, uint32_t my_base, uint32_t lane)
+{
+    uint32_t om[SNK_OTH_NPL];
+#pragma unroll
+    for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) {
+        const uint32_t j = lane + SNK_OTH_STR * i;
+        om[i] = j < SNK_OTH_SLOTS ? T.lut_omap[j] : 0u;
+    }
+    uint32_t sc[SNK_OTH_NSV];                                  // the saved set-case table of the current chain, then the next one's loads
+    {
+        const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(tm), flut, wave, lanes, chain0, my_base);
+#pragma unroll
+        for (uint32_t k = 0; k < SNK_OTH_NSV; ++k) { const uint32_t t = lane + SNK_OTH_STR * k; sc[k] = t < SNK_FCHAIN_B / 4u ? c.sv[t] : 0u; }
+    }
+    for (unsigned long long t2 = tm; t2; t2 &= t2 - 1ull) {
+        const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(t2), flut, wave, lanes, chain0, my_base);
+        const unsigned long long t3 = t2 & (t2 - 1ull);
+        const SnkOthChain n = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(t3 ? t3 : t2), flut, wave, lanes, chain0, my_base);
+        uint32_t *const r32 = (uint32_t *)c.region;
+        uint16_t *const tb = (uint16_t *)c.region;
+        uint32_t *const bmw = (uint32_t *)(c.region + SNK_FSLOTS * 2u);
+        uint32_t val[SNK_OTH_NPL];
+#pragma unroll
+        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) {                                     // the other-case entries: to the overflow table ...
+            const uint32_t j = lane + SNK_OTH_STR * i;
+            uint32_t v = 0u;
+            if (j < SNK_OTH_SLOTS) {
+                const uint32_t e = tb[j], b = (bmw[j >> 5] >> (j & 31u)) & 1u;
+                v = e | (b << 16);
+                // (an entry that is neither of this block nor in reach from it is dead for good: positions only grow.  Dead entries are
+                // zeroed at block ends from the third block on, where position 0 is out of reach too -- so 0 says the same)
+                if ((om[i] >> 16) == 0xFFFFu) c.ov[om[i] & 0xFFFu] = b ? c.base + e : (e ? c.base - 65536u + e : 0u);
+            }
+            val[i] = v;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SNK_OTH_NSV; ++k) {                                     // the set-case table back (and the next chain's on its way)
+            const uint32_t t = lane + SNK_OTH_STR * k;
+            if (t < SNK_FCHAIN_B / 4u) { r32[t] = sc[k]; sc[k] = n.sv[t]; }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) {                                     // ... or, shared hashes, into its slots (a slot put inside
+            const uint32_t j = lane + SNK_OTH_STR * i, sl = om[i] >> 16;                 // the stretch carries its bit; an untouched one is what it was)
+            if (j < SNK_OTH_SLOTS && sl != 0xFFFFu && (val[i] >> 16)) { tb[sl] = (uint16_t)val[i]; atomicOr(&bmw[sl >> 5], 1u << (sl & 31u)); }
+        }
+    }
 }
 
 // Rare path (once per 64 KiB): close the finished block, age the table, open the next block.
@@ -739,9 +881,10 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 #define SNK_STEADY_CONTRACT_FAR \
     "; snk-asm-contract inout %[c] %[wc] %[s1] %[s2] %[r0] %[r1] %[rbc] %[nxoff] %[anchor] %[op] %[opn] %[ns2] %[sm] %[sl]" \
     " | in %[lb] %[sx] %[kx] %[xoffB] %[yoffB] %[T0] %[limc] %[oz] %[dm] %[k8] %[arena] %[marena]" SNK_CONTRACT_BLK " %[gtb] %[ftab] %[vbm2] %[k17]\n\t"
-#define SNK_STEADY_TABLE \
-    SNK_STEADY_CONTRACT \
-    SNK_STEADY_ENTER \
+#define SNK_STEADY_TABLE SNK_STEADY_CONTRACT SNK_STEADY_ENTER SNK_STEADY_TABLE_BODY
+// (the other-case mode parks lanes inside the loop -- see SNK_STEADY_PARK_OTH -- and restores EXEC when it leaves)
+#define SNK_STEADY_TABLE_OTH SNK_STEADY_CONTRACT "s_mov_b64 %[se], exec\n\t" SNK_STEADY_TABLE_BODY
+#define SNK_STEADY_TABLE_BODY \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
@@ -897,7 +1040,31 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 #define SNK_STEADY_PARK
 #endif
 #define SNK_STEADY_REST_X(LIM, MASKOR) SNK_STEADY_REST_XX(LIM, MASKOR, "1", "0")
-#define SNK_STEADY_REST_XX(LIM, MASKOR, W1, W0) \
+#define SNK_STEADY_REST_XX(LIM, MASKOR, W1, W0) SNK_STEADY_REST_XXX(LIM, MASKOR, W1, W0, "")
+// (the other-case mode: the candidate's CLASS window must be 01 throughout -- XOR 0x55555555 joins the difference -- and the
+// slots come from the other case's LUT, 2 KiB further up in the LDS)
+#define SNK_STEADY_MASKOR_OTH \
+    "v_alignbit_b32 v119, v119, v118, v109\n\t" \
+    "v_xor_b32_e32 v119, 0x55555555, v119\n\t" \
+    "v_or_b32_e32 v113, v113, v119\n\t"
+// In the other-case mode the lanes of a wave walk the same stretch a few trips apart and each ends it at its own trip: a lane
+// whose ONLY reason to leave is its limit (the stretch's end, or the block's) is taken out of EXEC -- registers frozen in the
+// state every lane leaves the loop in -- and the others walk on; the wave leaves when a lane has another reason or none is
+// left.  (One wave exit per lane at the end of every stretch cost more than the stretch itself: 164 k cycles for ~95 trips.)
+#define SNK_STEADY_PARK_OTH \
+    "v_cmp_ge_u32_e64 %[ss], %[c], %[limc]\n\t"      /* the next cursor is at the lane's real limit */ \
+    "v_cmp_lt_i32_e32 vcc, 14, v125\n\t"             /* literal run, back-extension, output budget */ \
+    "s_andn2_b64 %[ss], %[ss], vcc\n\t"              /* the lanes to park */ \
+    "s_or_b64 vcc, vcc, %[st]\n\t" \
+    "s_andn2_b64 vcc, vcc, %[ss]\n\t"                /* a lane with another reason: leave */ \
+    "s_cbranch_vccnz .Lsnk_oleave%=\n\t" \
+    "s_andn2_b64 exec, exec, %[ss]\n\t" \
+    "s_cbranch_execnz 1b\n\t" \
+    ".Lsnk_oleave%=:\n\t" \
+    "s_mov_b64 exec, %[se]\n\t"
+#define SNK_STEADY_REST_OTH(LIM) SNK_STEADY_REST_CORE(LIM, SNK_STEADY_MASKOR_OTH, "1", "0", " offset:2048", SNK_STEADY_PARK_OTH)
+#define SNK_STEADY_REST_XXX(LIM, MASKOR, W1, W0, LUTOFF) SNK_STEADY_REST_CORE(LIM, MASKOR, W1, W0, LUTOFF, SNK_STEADY_PARK)
+#define SNK_STEADY_REST_CORE(LIM, MASKOR, W1, W0, LUTOFF, PARK) \
     "s_waitcnt vmcnt(" W1 ")\n\t" SNK_PADD \
     "v_alignbit_b32 v113, v107, v106, v109\n\t" \
     "v_xor_b32_e32 v113, v113, %[wc]\n\t" MASKOR \
@@ -918,10 +1085,10 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
     "v_alignbit_b32 %[wc], %[r1], %[r0], v116\n\t" \
     "v_lshrrev_b32_e32 v117, 7, %[wc]\n\t" \
     "v_and_b32_e32 v117, 0x7fe, v117\n\t" \
-    "ds_read_u16 %[s1], v117\n\t" \
+    "ds_read_u16 %[s1], v117" LUTOFF "\n\t" \
     "v_lshrrev_b32_e32 v118, 3, %[wc]\n\t" \
     "v_and_b32_e32 v118, 0x7fe, v118\n\t" \
-    "ds_read_u16 %[ns2], v118\n\t" SNK_PADE \
+    "ds_read_u16 %[ns2], v118" LUTOFF "\n\t" SNK_PADE \
     "v_ffbh_u32_e32 v120, v120\n\t" \
     "v_lshrrev_b32_e32 v120, 1, v120\n\t" \
     "v_min3_u32 v120, v120, %[lit], v111\n\t" \
@@ -933,7 +1100,7 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
     "v_cmp_ge_u32_e64 %[st], %[c], " LIM "\n\t" \
     "s_or_b64 vcc, vcc, %[st]\n\t" \
     "s_cbranch_vccz 1b\n\t" \
-    SNK_STEADY_PARK \
+    PARK \
     "s_waitcnt lgkmcnt(0)\n\t"
 #define SNK_STEADY_OPERANDS SNK_STEADY_OPERANDS_X()
 #define SNK_STEADY_OPERANDS_FAR SNK_STEADY_OPERANDS_X(, [gtb] "v"(gtb), [ftab] "s"(ftab), [vbm2] "v"(vb - 2u), [k17] "s"(131071))
@@ -997,19 +1164,22 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
                                                 const uint16_t *slot, uint32_t lds_off, uint32_t round_bases,
                                                 const uint16_t *okey SNK_PROF_ARG)
 {
-    static_assert(!OTH || (EXC && !ASM && !FAR), "the other-case mode exists as the C++ statement of the loop for sequences with exceptions");
+    static_assert(!OTH || (EXC && !FAR), "the other-case mode: sequences with exceptions, tables in LDS");
     SnkWin &w = L.w;                              // arena: the kernel argument (wave-uniform: the asm addresses it through SGPRs)
 #ifdef SNK_STATS
     const unsigned long long stat_te = clock64();
     const bool stat_first = (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
     (void)stat_first;
 #endif
+    // OTH: the chain's LDS region holds its OTHER-CASE table for the length of the stretch (snk_oth_swap_in), keyed by the other
+    // case's LUT, which the kernels for sequences with exceptions keep 2 KiB further up in the LDS
 #ifdef SNK_HOST_EMU
-    const uint16_t *const lut0 = slot;
+    const uint16_t *const lut0 = slot + (OTH ? 1024 : 0);
 #else
     (void)slot;                                   // the LUT sits at LDS address 0 (host checks: no static LDS)
-    const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0;
+    const SNK_AS3 uint16_t *const lut0 = (const SNK_AS3 uint16_t *)0 + (OTH ? 1024 : 0);
 #endif
+    (void)okey;
     const uint32_t vb = L.base;
     const int32_t T0 = (int32_t)(vb - 65536u);                    // stream position of t = 0
     const int32_t X0 = T0 - 4, Y0 = T0 - 4 - (int32_t)L.s.lx;    // source index of the window of t = 0
@@ -1037,13 +1207,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         r0 = sl ? r1 : r0; r1 = sl ? r2 : r1;
         rbc += sl ? 16u : 0u; nxoff += sl ? 4u : 0u;
         wc = __builtin_amdgcn_alignbit(r1, r0, 2u * no);
-        if (OTH) {
-            s1 = okey[(wc >> 8) & 1023u];
-            s2 = L.pending ? (uint32_t)okey[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);
-        } else {
-            s1 = lut0[(wc >> 8) & 1023u];
-            s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
-        }
+        s1 = lut0[(wc >> 8) & 1023u];
+        s2 = L.pending ? (uint32_t)lut0[(wc >> 4) & 1023u] : (SNK_FSLOTS - 1u);     // nothing owed: the unused slot
     }
     uint32_t t; bool valid;
 #ifdef SNK_STATS
@@ -1079,6 +1244,13 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
             else
                 asm volatile(SNK_STEADY_TABLE_FAR SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW_FAR("v103") SNK_STEADY_STRADDLE SNK_STEADY_REST_FAR("v105")
                              SNK_STEADY_OPERANDS_FAR);
+        } else if (OTH) {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_STEADY_TABLE_OTH SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW_X("%[t]", SNK_STEADY_MASKLOAD)
+                             SNK_STEADY_REST_OTH("%[limc]") SNK_STEADY_OPERANDS);
+            else
+                asm volatile(SNK_STEADY_TABLE_OTH SNK_STEADY_ADDR_DUAL SNK_STEADY_SHADOW_X("v103", SNK_STEADY_MASKLOAD) SNK_STEADY_STRADDLE
+                             SNK_STEADY_REST_OTH("v105") SNK_STEADY_OPERANDS);
         } else if (!EXC || !need_mask) {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_STEADY_TABLE SNK_STEADY_ADDR_YONLY SNK_STEADY_SHADOW("%[t]") SNK_STEADY_REST("%[limc]")
@@ -1106,20 +1278,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
 #ifdef SNK_STATS
         if (OTH) stat_otrips++;
 #endif
-        if (OTH) {      // keys: < 896 a slot of the 2-bit table (u16 + bitmap), else 0x1000 | hash: the overflow table (absolute)
-            if (s2 < SNK_FSLOTS) { tbl[s2] = (uint16_t)(c - 2u); atomicOr(&bm[s2 >> 5], 1u << (s2 & 31u)); }
-            else                 L.ovf[s2 & 0xFFFu] = vb + c - 2u;
-            if (s1 < SNK_FSLOTS) {
-                const uint32_t e = tbl[s1];
-                const uint32_t bw = atomicOr(&bm[s1 >> 5], 1u << (s1 & 31u));
-                tbl[s1] = (uint16_t)c;
-                t = e + (((bw >> (s1 & 31u)) & 1u) << 16);
-            } else {
-                const int32_t ts = (int32_t)(L.ovf[s1 & 0xFFFu] - (uint32_t)T0);
-                L.ovf[s1 & 0xFFFu] = vb + c;
-                t = ts < 0 ? 0u : (ts > 131071 ? 131071u : (uint32_t)ts);
-            }
-        } else if (FAR) {                                         // absolute positions in global memory, liblz4's order
+        if (FAR) {                                                // absolute positions in global memory, liblz4's order
             gt[s2] = vb + c - 2u;
             const int32_t ts = (int32_t)(gt[s1] - (uint32_t)T0);
             gt[s1] = vb + c;
@@ -1162,8 +1321,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
         const bool sl = no >= 16u;
         const uint32_t lo = sl ? r1 : r0, hi = sl ? r2 : r1;
         const uint32_t nwc = __builtin_amdgcn_alignbit(hi, lo, 2u * no);
-        const uint32_t ns1 = OTH ? okey[(nwc >> 8) & 1023u] : lut0[(nwc >> 8) & 1023u];
-        const uint32_t ns2 = OTH ? okey[(nwc >> 4) & 1023u] : lut0[(nwc >> 4) & 1023u];
+        const uint32_t ns1 = lut0[(nwc >> 8) & 1023u];
+        const uint32_t ns2 = lut0[(nwc >> 4) & 1023u];
 
         // ---- this probe's accounting, in the shadow of the LUT reads ----
         const uint32_t eq = (uint32_t)__builtin_clz(((x & 0xFFu) << 24) | 0x00800000u) >> 1;   // equal bases before cur, 0..4
@@ -1186,9 +1345,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
             if (straddle) SNK_COUNT(22);
         }
 #endif
-        // one wave-uniform exit; in the other-case mode (compiled code, a stretch is ~100 trips) a lane that needs service
-        // or has reached the end of its stretch leaves alone and the others walk on
-        if (OTH ? svc : __builtin_amdgcn_ballot_w64(svc) != 0ull) break;
+        // one wave-uniform exit
+        if (__builtin_amdgcn_ballot_w64(svc) != 0ull) break;
 
         // ---- commit ----
         op = m ? opn : op; anchor_c = m ? ncur : anchor_c;
@@ -1842,6 +2000,9 @@ struct SnkFastGrid {
     uint32_t lds_waves = 0, far_lanes = 0;
     uint32_t far_stop = 0;    // a far wave takes no further jobs once fewer than this many are left in the queue (the
                               // LDS waves finish them sooner than a far chain would)
+    uint32_t short_last = 0;  // 1: the last wave of every workgroup runs one chain fewer (sets with other-case stretches: the
+                              // second LUT leaves room for 83 chains, not 84 -- 21 + 21 + 21 + 20)
+    uint32_t flut = SNK_FLUT_B;   // LDS bytes in front of the chains: the slot LUT, and (sets with other-case letters) the other case's
 };
 
 __device__ __forceinline__ SnkJob snk_fast_job(const SnkFastGrid &G, uint32_t q)
@@ -1905,15 +2066,18 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 
 #ifdef SNK_STATS
     const unsigned long long stat_w0 = clock64(), stat_wall0 = wall_clock64();      // (wall clock: constant 100 MHz -> the shader clock of the run)
-    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
+    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
     // the chain of the wave this lane belongs to (TRI: rows of 16 lanes = 5 chains x 3 lanes, lane 15 idles), and its role in it
     const uint32_t role = TRI ? ((lane & 15u) == 15u ? 3u : (lane & 15u) % 3u) : SPEC ? (lane & 1u) : 0u;
     const uint32_t cidx = TRI ? (lane >> 4) * 5u + (lane & 15u) / 3u : SPEC ? lane >> 1 : lane;
-    const bool lane_on = role == 0u && cidx < lanes && (!TRI || (lane & 15u) != 15u);   // ... and runs (the other roles only inside the steady loop)
+    const bool lane_on = role == 0u && cidx < lanes - ((G.short_last && wave + 1u == waves) ? 1u : 0u) &&
+                         (!TRI || (lane & 15u) != 15u);                            // ... and runs (the other roles only inside the steady loop)
     // LDS waves: the chain's table at LDS address mine_off (dynamic LDS starts at 0).  FAR waves: at word far_idx * 896 of G.far_tab.
-    const uint32_t mine_off = FAR ? 0u : SNK_FLUT_B + (wave * lanes + (cidx < lanes ? cidx : 0u)) * SNK_FCHAIN_B;
+    // (when the resident set has letters of the other case the kernels keep TWO LUTs in front of the chains: G.flut = 4096)
+    const uint32_t flut = EXC ? G.flut : SNK_FLUT_B;
+    const uint32_t mine_off = FAR ? 0u : flut + (wave * lanes + (cidx < lanes ? cidx : 0u)) * SNK_FCHAIN_B;
     uint8_t *const mine = snk_lds8 + mine_off;
     uint16_t *const tbl = (uint16_t *)mine;
     uint32_t *const bm = (uint32_t *)(mine + SNK_FSLOTS * 2u);
@@ -1921,7 +2085,6 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
     uint32_t *const gt = FAR ? G.far_tab + (size_t)(far_wave0 + (lane_on ? lane : 0u)) * SNK_FSLOTS : nullptr;
     const uint32_t gtb = FAR ? (far_wave0 + (lane_on ? lane : 0u)) * (SNK_FSLOTS * 4u) : 0u;                   // ... as a byte offset
 
-    const uint32_t n_batches = (G.n_jobs + G.batch - 1u) / G.batch;
     const uint32_t wid = blockIdx.x * waves + wave, wtotal = gridDim.x * waves;
     uint32_t bcur = wid;                         // wave-uniform: the batch the wave takes next (its first: its own number)
     bool first = true;
@@ -1947,7 +2110,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 // (measured at 336 rows x 1024: 100 IUPAC codes per Mbp 62 -> 74 % of the pure rate, the rest unchanged)
                 if (EXC && __any(have)) break;
                 if (G.queue) {           // dynamic: the next jobs of the launch, as many as the wave has chains
-                    const uint32_t want = FAR ? lanes : G.batch;
+                    const uint32_t want = FAR ? lanes : G.batch - ((G.short_last && wave + 1u == waves) ? 1u : 0u);      // (as many as the wave has chains)
                     uint32_t b = 0xFFFFFFFFu;
                     // (FAR) near the end of the launch the LDS waves finish what is left sooner than a far chain would
                     if (lane == 0u && !(FAR && G.far_stop && *(volatile uint32_t *)G.queue + G.far_stop >= G.n_jobs))
@@ -1958,9 +2121,13 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 } else {
                     if (first) first = false;
                     else bcur += wtotal;
-                    if (bcur >= n_batches) { dry = true; break; }
-                    wb = bcur * G.batch;
-                    we = wb + G.batch < G.n_jobs ? wb + G.batch : G.n_jobs;
+                    // (a workgroup takes `cwg` consecutive jobs at a time, wave w of it those from w * batch on: the same as batch
+                    // number bcur when every wave has `batch` chains, and one column of 83 rows for 21 + 21 + 21 + 20 chains)
+                    const uint32_t cwg = G.batch * waves - G.short_last;
+                    const uint32_t mine_n = G.batch - ((G.short_last && wave + 1u == waves) ? 1u : 0u);
+                    wb = (bcur / waves) * cwg + wave * G.batch;
+                    if (wb >= G.n_jobs) { dry = true; break; }
+                    we = wb + mine_n < G.n_jobs ? wb + mine_n : G.n_jobs;
                 }
             }
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
@@ -1975,7 +2142,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 const int xi  = __shfl(job.xi, (int)l);
                 const int snp = __shfl(job.snap, (int)l);
                 const uint32_t lc = TRI ? (l >> 4) * 5u + (l & 15u) / 3u : SPEC ? l >> 1 : l;      // the chain of lane l
-                uint8_t *dst = snk_lds8 + SNK_FLUT_B + (size_t)(wave * lanes + lc) * SNK_FCHAIN_B;
+                uint8_t *dst = snk_lds8 + flut + (size_t)(wave * lanes + lc) * SNK_FCHAIN_B;
                 const uint32_t spos = T.snap_pos[xi];
                 const bool use = (snp == 0) && (spos != 0u);
                 const uint32_t *src = T.snap_fast + (size_t)xi * SNK_FSLOTS;
@@ -2039,6 +2206,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 atomicAdd(&S[24], P.finish); atomicAdd(&S[25], P.rounds_cyc); atomicAdd(&S[26], (unsigned long long)P.rounds);
                 atomicAdd(&S[27], P.prologue); atomicAdd(&S[28], P.probe); atomicAdd(&S[29], P.top);
                 atomicAdd(&S[30], (unsigned long long)P.jobs); atomicAdd(&S[31], 1ull); atomicAdd(&S[23], P.other); atomicAdd(&S[48], P.otrips); atomicAdd(&S[49], P.olanes); atomicAdd(&S[50], (unsigned long long)P.oruns);
+                atomicAdd(&S[59], P.oin); atomicAdd(&S[60], P.oout); atomicAdd(&S[61], (unsigned long long)P.oswaps);
             }
 #endif
             return;
@@ -2107,22 +2275,40 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 // loop's other-case mode instead of one general probe per round -- TOGETHER: the lanes gathered at the site reach
                 // the stretch proper a few general probes apart, so the mode starts once no served lane needs a general probe any
                 // more (else the first lane to arrive would walk its whole stretch alone, then the next one, ...)
-                oel = !ok && L.cur + L.step <= L.mfl1 && L.step == 1u && L.nb < 63u + SNK_FAST_MAXLIT &&
+                oel = !ok && flut > SNK_FLUT_B && L.cur + L.step <= L.mfl1 && L.step == 1u && L.nb < 63u + SNK_FAST_MAXLIT &&
                       L.op + SNK_FAST_ZONE <= L.olimit && L.cur >= L.xlim && snk_exc_other_ready(L);
                 if (__any(oel) && !__any(!ok && !oel)) {
 #ifdef SNK_STATS
                     const unsigned long long stat_q0 = clock64();
 #endif
-                    if (oel) {
-                        const uint32_t cur = L.cur, lx = L.s.lx;
-                        if (cur >= lx + 4u) snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
-                        else                snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
-                        if (L.mask_until < L.olim + 65536u) L.mask_until = L.olim + 65536u;     // its puts point into the stretch
-                        snk_fast_steady<false, true, false, true>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)T.mask_arena, tbl, bm, gt,
-                                                                  (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu, T.lut_okey SNK_PROF_PASS);
+                    // the chains of these lanes swap tables (every lane of the wave helps with every chain), walk their stretches in the
+                    // other-case mode -- all together, re-entering after a service that leaves a lane inside its stretch with an
+                    // ordinary next probe (finishing a probe touches no table) --, and swap back
+                    const unsigned long long om_ = __builtin_amdgcn_ballot_w64(oel);
+                    snk_oth_swap_in_all<SPEC>(T, snk_lds8, om_, flut, wave, lanes, (size_t)(blockIdx.x * waves + wave) * lanes, L.base, lane);
+#ifdef SNK_STATS
+                    const unsigned long long stat_q1 = clock64();
+                    P.oin += stat_q1 - stat_q0; P.oswaps++;
+#endif
+                    bool inm = oel;
+                    while (__any(inm)) {
+                        if (inm) {
+                            const uint32_t cur = L.cur, lx = L.s.lx;
+                            if (cur >= lx + 4u) snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
+                            else                snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
+                            if (L.mask_until < L.olim + 65536u) L.mask_until = L.olim + 65536u;     // its puts point into the stretch
+                            snk_fast_steady<ASM, true, false, true>(L, (snk_g8 *)T.packed_arena, (snk_g8 *)T.mask_arena, tbl, bm, gt,
+                                                                    (SNK_AS1 uint32_t *)G.far_tab, gtb, slot, mine_off, 0xFFFFFFFFu, T.lut_okey SNK_PROF_PASS);
+                            inm = L.cur - L.olo < L.olim - L.olo && L.cur + L.step <= L.mfl1 && L.step == 1u &&
+                                  L.nb < 63u + SNK_FAST_MAXLIT && L.op + SNK_FAST_ZONE <= L.olimit;
+                        }
                     }
 #ifdef SNK_STATS
-                    P.other += clock64() - stat_q0;
+                    const unsigned long long stat_q2 = clock64();
+#endif
+                    snk_oth_swap_out_all<SPEC>(T, snk_lds8, om_, flut, wave, lanes, (size_t)(blockIdx.x * waves + wave) * lanes, L.base, lane);
+#ifdef SNK_STATS
+                    P.other += clock64() - stat_q0; P.oout += clock64() - stat_q2;
 #endif
                     continue;
                 }
@@ -2207,6 +2393,9 @@ __device__ __forceinline__ void snk_fast_kernel_body(const SnkTables &T, const S
 #endif
     for (uint32_t t = threadIdx.x; t < 512u; t += SNK_COOP(blockDim.x))
         ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    if (EXC && G.flut > SNK_FLUT_B)               // the other case's LUT (the other-case mode of the steady loop)
+        for (uint32_t t = threadIdx.x; t < 512u; t += SNK_COOP(blockDim.x))
+            ((uint32_t *)snk_lds8)[512u + t] = ((const uint32_t *)T.lut_oj)[t];
     __syncthreads();
     if (!EXC && G.far_lanes != 0u && (threadIdx.x >> 6) >= G.lds_waves)
         snk_fast_wave<ASM, false, true>(T, G, G.far_lanes, out, status);
@@ -2287,8 +2476,10 @@ template <bool ASM>
 __device__ __forceinline__ void snk_fastx_spec_body(const SnkTables &T, const SnkFastGrid &G, uint32_t lanes, uint32_t *out, uint32_t *status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t snk_lds8[];
-    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x)
+    for (uint32_t t = threadIdx.x; t < 512u; t += blockDim.x) {
         ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+        if (G.flut > SNK_FLUT_B) ((uint32_t *)snk_lds8)[512u + t] = ((const uint32_t *)T.lut_oj)[t];         // the other case's LUT
+    }
     __syncthreads();
     snk_fast_wave<ASM, true, false, true>(T, G, lanes, out, status);
 }

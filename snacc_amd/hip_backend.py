@@ -103,12 +103,13 @@ def load():
     L.snk_num_compact_hashes.argtypes = [vp]
     L.snk_singles.restype = i32
     L.snk_singles.argtypes = [vp, u32p]
-    L.snk_singles_rows.restype = i32
-    L.snk_singles_rows.argtypes = [vp, i32, i32, u32p]
-    L.snk_upload_times.restype = i32
-    L.snk_upload_times.argtypes = [vp, vp, i32]
-    L.snk_ncd_matrix_u32.restype = i32
-    L.snk_ncd_matrix_u32.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, vp, i32]
+    if hasattr(L, "snk_singles_rows"):          # (absent from the round-3 builds that development A/B runs load through SNACC_HIP_LIB)
+        L.snk_singles_rows.restype = i32
+        L.snk_singles_rows.argtypes = [vp, i32, i32, u32p]
+        L.snk_upload_times.restype = i32
+        L.snk_upload_times.argtypes = [vp, vp, i32]
+        L.snk_ncd_matrix_u32.restype = i32
+        L.snk_ncd_matrix_u32.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, vp, i32]
     L.snk_pairs.restype = i32
     L.snk_pairs.argtypes = [vp, i32, i32, u32p]
     L.snk_pairs_device.restype = i32

@@ -30,6 +30,7 @@ template <bool EXC> static void emu_launch(const SnkTables &T, const SnkFastGrid
 {
     if (!spec) { snk_fast_kernel_body<false, EXC>(T, G, 1u, out, status); return; }
     for (uint32_t t = 0; t < 512u; ++t) ((uint32_t *)snk_lds8)[t] = ((const uint32_t *)T.lut_slot)[t];
+    if (EXC && G.flut > SNK_FLUT_B) for (uint32_t t = 0; t < 512u; ++t) ((uint32_t *)snk_lds8)[512u + t] = ((const uint32_t *)T.lut_oj)[t];
     snk_fast_wave<false, EXC, false, true>(T, G, 1u, out, status);
 }
 
@@ -59,6 +60,24 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         for (int i = 0; i < 5; ++i) b[i] = (uint8_t)(code2byte[(k >> (2 * i)) & 3] ^ 0x20);
         const uint32_t h = host_hash5(b);
         okey[k] = h2s[h] != 0xFFFF ? h2s[h] : (uint16_t)(0x1000u | h);
+    }
+    // the other case's own numbering of its hashes (the other-case mode keeps its table in LDS: snk_oth_swap_in), and both LUTs
+    // back to back as the kernels for sequences with exceptions hold them in LDS
+    std::vector<uint16_t> oj(1024, 0), luts(2048, 0);
+    std::vector<uint32_t> omap(SNK_FSLOTS, 0xFFFF0000u);
+    {
+        std::vector<int> cls(4096, -1);
+        int ncls = 0;
+        for (uint32_t k = 0; k < 1024; ++k) {
+            uint8_t b[5];
+            for (int i = 0; i < 5; ++i) b[i] = (uint8_t)(code2byte[(k >> (2 * i)) & 3] ^ 0x20);
+            const uint32_t h = host_hash5(b);
+            if (cls[h] < 0) cls[h] = ncls++;
+            oj[k] = (uint16_t)cls[h];
+            omap[(size_t)cls[h]] = h | ((uint32_t)h2s[h] << 16);
+        }
+        if (ncls >= (int)SNK_FSLOTS) return -1;
+        for (uint32_t k = 0; k < 1024; ++k) { luts[k] = slot[k]; luts[1024 + k] = oj[k]; }
     }
     std::vector<uint8_t> ok((size_t)n, 0), exc((size_t)n, 0);
     std::vector<uint32_t> poff((size_t)n, 0), boff((size_t)n, 0), len((size_t)n), spos((size_t)n), eoff((size_t)n, 0xFFFFFFFFu);
@@ -111,7 +130,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         }
     }
     std::vector<uint32_t> snap_out((size_t)n, 0), snap_fast((size_t)n * SNK_FSLOTS, 0), snap_gen((size_t)n * 4096, 0), status(1, 0);
-    std::vector<uint32_t> ovf(4096, 0);
+    std::vector<uint32_t> ovf(4096, 0), osave(512, 0);
     // exact runs of non-ACGT bytes of the sequences with exceptions (as snk_upload builds them)
     std::vector<uint32_t> runs, roff((size_t)n, 0);
     for (int g = 0; g < n; ++g) {
@@ -131,6 +150,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     T.packed_arena = arena.data(); T.mask_arena = marena.data(); T.packed_off = poff.data(); T.len = len.data();
     T.bytes_arena = bytes.data(); T.bytes_off = boff.data(); T.zero_pad = zero.data();
     T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data(); T.snap_gen = snap_gen.data();
+    T.lut_oj = oj.data(); T.lut_omap = omap.data(); T.osave = osave.data();
     T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.lut_okey = okey.data(); T.header_bytes = header_bytes;
     T.exc_flags = fl.data(); T.exc_off = eoff.data(); T.ovf = ovf.data(); T.exc_runs = runs.data(); T.exc_roff = roff.data();
 
@@ -140,6 +160,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         if (!ok[g] || lens[g] <= SNK_BLOCK) continue;
         SnkJob jb; jb.xi = g; jb.yi = -1; jb.out_idx = (uint32_t)g; jb.snap = spos[g] ? 1 : 0;
         SnkFastGrid G; G.jobs = &jb; G.n_jobs = 1u; G.r0 = 0u; G.rows = 1u; G.n = 1u; G.batch = 1u; G.queue = nullptr; G.yorder = nullptr;
+        if (any_exc) G.flut = 2u * SNK_FLUT_B;
         if (any_exc) emu_launch<true>(T, G, singles, status.data(), spec != 0);
         else         emu_launch<false>(T, G, singles, status.data(), spec != 0);
     }
@@ -156,6 +177,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         }
     if (!list.empty()) {
         SnkFastGrid G; G.r0 = 0u; G.rows = (uint32_t)n; G.n = (uint32_t)n; G.batch = 3u;
+        if (any_exc) G.flut = 2u * SNK_FLUT_B;
         std::vector<uint32_t> order((size_t)n);
         for (int k = 0; k < n; ++k) order[(size_t)k] = (uint32_t)(n - 1 - k);
         G.yorder = (n & 2) ? order.data() : nullptr;

@@ -63,7 +63,18 @@ def test_every_loop_carries_its_contract(device_asm):
     """No hand-scheduled loop goes without a contract line: each table read of a loop (`ds_or_rtn_b32 ... offset:1792`, the
     first LDS instruction of a trip) has the contract comment of its asm statement a few lines above it."""
     lines = device_asm.splitlines()
-    reads = [i for i, ln in enumerate(lines) if "ds_or_rtn_b32" in ln and "offset:1792" in ln]
+    # (the hand-scheduled loops read through their hard temporaries: v94 <- [v92] | v93 / v99; compiled C++ statements of the same
+    # table read use whatever registers the compiler picked)
+    reads = [i for i, ln in enumerate(lines) if re.search(r"ds_or_rtn_b32 v94, v92, v9[39] offset:1792", ln)]
     assert len(reads) >= 14, len(reads)
     for i in reads:
-        assert any("snk-asm-contract" in ln for ln in lines[max(0, i - 24):i]), lines[max(0, i - 24):i + 1]
+        assert any("snk-asm-contract" in ln for ln in lines[max(0, i - 40):i]), lines[max(0, i - 40):i + 1]
+
+
+def test_the_2bit_kernels_use_no_scratch(device_asm):
+    """Every 2-bit kernel keeps its state in registers: a kernel that spills loses the schedule the loops were written for, and
+    the one time a build of the exception kernels spilled (round 4: 12 bytes per lane, while the table swaps of the other-case
+    mode were being written) it faulted on the card.  The compiler's own figure, from the generated code."""
+    sizes = dict(re.findall(r"\.set (_Z\d+snk_fast\w+)\.private_seg_size, (\d+)", device_asm))
+    assert len(sizes) >= 14, sorted(sizes)
+    assert all(v == "0" for v in sizes.values()), {k: v for k, v in sizes.items() if v != "0"}

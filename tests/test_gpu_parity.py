@@ -48,7 +48,7 @@ def test_phase_a_on_demand_per_row_and_spread_over_the_card(hip, oracle_mod):
     pure = [o.lcg_genome(61 + i, 200000 + 4099 * i) for i in range(7)]
     exp_ps = np.array([o.lz4f_size(x) for x in pure], dtype=np.uint32)
     exp_pp = np.array([[o.lz4f_size_pair(a, b) for b in pure] for a in pure], dtype=np.uint32)
-    for opts in ({}, {"fast_spec": 0}, {"fast_lanes": 3}, {"fast_lanes": 21, "fast_spec": 0}):
+    for opts in ({}, {"fast_spec": 0}, {"fast_lanes": 3}, {"fast_lanes": 20, "fast_spec": 0}):     # (a set with exceptions holds 83 chains per CU: 4 x 21 do not fit)
         with hip.HipContext(0, **opts) as ctx:
             ctx.upload(pure)
             assert np.array_equal(ctx.singles(), exp_ps), opts
@@ -486,7 +486,7 @@ def test_exceptions_at_the_bench_shape_1mbp_84_chains(hip, oracle_mod):
         seqs.append(a)
     with hip.HipContext(0) as ctx:
         ctx.upload(seqs)
-        assert ctx.num_packed == n and ctx.fast_chains() == 84
+        assert ctx.num_packed == n and ctx.fast_chains() == 83      # (a set with exceptions: the other case's LUT takes the 84th chain's room)
         s, p = ctx.singles(), ctx.pairs(0, 84)
     assert np.array_equal(s[:4], np.array([o.lz4f_size(x) for x in seqs[:4]], dtype=np.uint32))
     want = pairs_mt(seqs, 0, 84, _threads())

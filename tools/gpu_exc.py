@@ -59,6 +59,9 @@ for kind in KINDS:
         if st[23]:
             print(f"   other-case mode: {st[23] / st[7]:.1%} of the wave cycles; {int(st[50]):,} runs, {st[48] / max(1, st[50]):.0f} wave trips per run, "
                   f"{st[49] / max(1, st[48]):.1f} lanes per trip, {st[23] / max(1, st[48]):,.0f} cycles per wave trip")
+        if st[61]:
+            print(f"   table swaps (other-case mode on a table in LDS): {int(st[61]):,} per first lanes; in {st[59] / st[61]:,.0f} cycles, out {st[60] / st[61]:,.0f}, "
+                  f"whole mode {st[23] / st[61]:,.0f} per swap; lanes in the mode per swap: {st[49] / max(1, st[48]):.1f}")
         if st[14]:
             print(f"   wave cycles {int(st[7]):,}: in the loop {st[13] / st[7]:.1%}, loop entries {int(st[14]):,}, per entry: outside {(st[7] - st[13]) / st[14]:,.0f} cycles"
                   f" (finish {st[24] / st[14]:,.0f}, general rounds {st[25] / st[14]:,.0f} in {st[26] / st[14]:.2f} rounds)"
