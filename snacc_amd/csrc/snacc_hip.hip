@@ -338,11 +338,13 @@ int fast_geometry(snk_ctx_impl *c, uint32_t *lanes_out, uint32_t *short_last = n
     if (lanes == 0u) {
         lanes = (uint32_t)((160 * 1024 - (size_t)SNK_FLUT_B) / ((size_t)waves * SNK_FCHAIN_B));
         if (lanes > 64u) lanes = 64u;
-        if (lut_b + (size_t)lanes * waves * SNK_FCHAIN_B > 160 * 1024) {
-            if (lanes > 1u && lut_b + ((size_t)lanes * waves - 1u) * SNK_FCHAIN_B <= 160 * 1024) shortl = 1u;
-            else lanes = (uint32_t)((160 * 1024 - lut_b) / ((size_t)waves * SNK_FCHAIN_B));
-        }
+        if (lut_b + (size_t)lanes * waves * SNK_FCHAIN_B > 160 * 1024 &&
+            !(lanes > 1u && lut_b + ((size_t)lanes * waves - 1u) * SNK_FCHAIN_B <= 160 * 1024))
+            lanes = (uint32_t)((160 * 1024 - lut_b) / ((size_t)waves * SNK_FCHAIN_B));
     }
+    // (one chain too many for the LDS -- 4 x 21 beside two LUTs: the last wave runs one fewer)
+    if (lanes > 1u && lut_b + (size_t)lanes * waves * SNK_FCHAIN_B > 160 * 1024 && lut_b + ((size_t)lanes * waves - 1u) * SNK_FCHAIN_B <= 160 * 1024)
+        shortl = 1u;
     if (lanes == 0u || lut_b + ((size_t)lanes * waves - shortl) * SNK_FCHAIN_B > 160 * 1024)
         return fail(c, SNK_E_ARG, "fast_lanes*fast_waves = %u chains exceed the 160 KiB LDS (max %d)", lanes * waves, c->any_other ? 83 : 84);
     *lanes_out = lanes;
