@@ -83,10 +83,10 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   per CU and launch (default 1; the host launches ceil(jobs / capacity) times, one table per chain)
  *   "bytes_legacy"  1 = linked-mode byte jobs use the legacy u32-table kernel (testing)
  *   "exc_limit"     a sequence with bytes other than ACGT (acgt in a set that is mostly lower case) -- N runs, IUPAC codes,
- *                   stretches in the other case -- stays on the 2-bit
- *                   kernel while at most 8 * exc_limit of its 16-base granules per 2^20 bases hold one and it has at most
- *                   4 + 1.25 * exc_limit such runs per 2^20 bases (default 2048: 25 % of the granules, 2564 runs per
- *                   Mbp -- beyond that the byte kernels are faster); 0 = pure ACGT only.  Set before snk_upload.
+ *                   stretches in the other case -- stays on the 2-bit kernel while it has at most 4 + 1.25 * exc_limit RUNS of
+ *                   such bytes per 2^20 bases (default 2048: 2564 runs per Mbp -- beyond that the byte kernels are faster);
+ *                   how many bases the runs cover does not matter (round 4: soft-masked genomes run faster on the 2-bit kernel
+ *                   at every density); 0 = pure ACGT only.  Set before snk_upload.
  *   "fast_dynamic"  -1 auto / 0 static round robin / 1 atomic queue: how the waves of the 2-bit kernel take their batches
  *   "far_lanes", "far_waves", "far_min", "far_stop_pct"  chains of the 2-bit kernel beyond the LDS (extra waves whose chains
  *                   keep their tables in global memory; far_lanes 0 = none, the default).  A measured negative kept for

@@ -80,9 +80,9 @@ struct snk_ctx_impl {
     bool any_exc = false;
     bool any_other = false;          // ... and some exception byte of a 2-bit sequence is a letter of the other case (soft-masked stretches)
     bool lower = false;              // the resident set's letters are acgt: its 2-bit sequences, LUTs and exceptions go by the lower case
-    long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 8 * exc_limit flagged 16-base granules (25 % of
-                                     // them at 2048) and 4 + 1.25 * exc_limit sites per 2^20 bases (see snk_upload); beyond that the
-                                     // byte kernels are faster (measured crossover: 27 % soft-masked, 2400 IUPAC sites per Mbp)
+    long exc_limit = 2048;           // a sequence stays on the 2-bit kernel up to 4 + 1.25 * exc_limit exception sites (runs of bytes that
+                                     // are not the set's letters) per 2^20 bases (see snk_upload); beyond that the byte kernels are
+                                     // faster (measured crossover: 2400 IUPAC sites per Mbp; soft-masking: never, round 4)
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
     uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr, *d_lut_okey = nullptr;
@@ -1048,46 +1048,67 @@ static int upload_impl(snk_ctx *c, int n_seq, const uint8_t *const *seqs, const 
     c->is_packed.assign(n, 0); c->has_exc.assign(n, 0); c->any_exc = false; c->any_other = false;
     std::vector<uint32_t> eoff(n, 0xFFFFFFFFu), runs, roff(n, 0);
     {
+        // Round 4: with the other-case mode on a table in LDS the 2-bit kernel is faster than the byte kernels at EVERY density of
+        // soft-masking measured (1024 x 1 Mbp, 30 / 40 / 60 % lower case: 107 k / 93 k / 79 k against 62 k pair-compr./s), so the share
+        // of flagged granules no longer decides -- only the number of exception SITES does (every site costs general probes:
+        // 4 + 1.25 * exc_limit runs per 2^20 bases, 2 564 per Mbp at the default; measured crossover for scattered IUPAC codes 2 400).
         std::vector<uint32_t> raw_all;                      // the raw granule flags of every sequence: ONE copy, when a candidate has any
         bool want_raw = false;
         for (size_t g = 0; g < n; ++g) {
-            const uint64_t allowed = 8u + (uint64_t)lens[g] * (uint64_t)c->exc_limit * 8u / 1048576u;     // granules: a first sieve
-            c->is_packed[g] = lens[g] > 0 && (ecount[g] == 0 || (c->exc_limit > 0 && ecount[g] <= allowed));
+            c->is_packed[g] = lens[g] > 0 && (ecount[g] == 0 || c->exc_limit > 0);
             want_raw |= c->is_packed[g] && ecount[g] != 0;
         }
         if (want_raw) {
             raw_all.resize(ftot);
             HIPCHK(c, hipMemcpy(raw_all.data(), d_raw, ftot * 4, hipMemcpyDeviceToHost));
         }
+        // the exact runs of exception bytes of every candidate, from the caller's bytes of its flagged granules: host threads, one
+        // sequence at a time each (a set of 60 % soft-masked genomes has 600 MB to look at)
+        std::vector<std::vector<uint32_t>> seq_runs(n);
+        std::vector<uint8_t> seq_other(n, 0), seq_ok(n, 0);
+        {
+            std::atomic<size_t> next(0);
+            auto work = [&]() {
+                for (;;) {
+                    const size_t g = next.fetch_add(1);
+                    if (g >= n) return;
+                    if (!c->is_packed[g] || ecount[g] == 0) continue;
+                    const uint32_t *raw = raw_all.data() + foff[g];
+                    std::vector<uint32_t> &rr = seq_runs[g];
+                    const uint64_t max_sites = 4u + (uint64_t)lens[g] * 160u / 1048576u * (uint64_t)c->exc_limit / 128u;
+                    bool other = false, ok = true;
+                    for (size_t w = 0; w < fwords[g] && ok; ++w) {
+                        uint32_t bits = raw[w];
+                        while (bits) {
+                            const size_t gr = w * 32 + (size_t)__builtin_ctz(bits);
+                            bits &= bits - 1;
+                            for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
+                                const uint8_t ch = seqs[g][i];
+                                if (ch == ('A' | lcase) || ch == ('C' | lcase) || ch == ('G' | lcase) || ch == ('T' | lcase)) continue;
+                                { const uint8_t u = (uint8_t)(ch & ~0x20u); other |= (u == 'A' || u == 'C' || u == 'G' || u == 'T'); }
+                                if (!rr.empty() && rr.back() == (uint32_t)i) rr.back() = (uint32_t)i + 1;       // extends the open run
+                                else { rr.push_back((uint32_t)i); rr.push_back((uint32_t)i + 1); }
+                            }
+                        }
+                        if (rr.size() / 2 > max_sites) ok = false;                 // too many: the byte kernel serves this one
+                    }
+                    seq_ok[g] = ok; seq_other[g] = other;
+                }
+            };
+            const size_t nt = want_raw ? std::min<size_t>(16, std::max<size_t>(1, std::min<size_t>(n, std::thread::hardware_concurrency()))) : 1;
+            std::vector<std::thread> ts;
+            for (size_t t = 1; t < nt; ++t) ts.emplace_back(work);
+            work();
+            for (auto &th : ts) th.join();
+        }
         for (size_t g = 0; g < n; ++g) {
             if (!c->is_packed[g] || ecount[g] == 0) continue;
-            const uint32_t *raw = raw_all.data() + foff[g];
-            const size_t first = runs.size();
-            bool other = false;                                        // a letter of the other case among this sequence's exceptions
-            for (size_t w = 0; w < fwords[g]; ++w) {
-                uint32_t bits = raw[w];
-                while (bits) {
-                    const size_t gr = w * 32 + (size_t)__builtin_ctz(bits);
-                    bits &= bits - 1;
-                    for (size_t i = gr * 16; i < gr * 16 + 16 && i < lens[g]; ++i) {
-                        const uint8_t ch = seqs[g][i];
-                        if (ch == ('A' | lcase) || ch == ('C' | lcase) || ch == ('G' | lcase) || ch == ('T' | lcase)) continue;
-                        { const uint8_t u = (uint8_t)(ch & ~0x20u); other |= (u == 'A' || u == 'C' || u == 'G' || u == 'T'); }
-                        if (runs.size() > first && runs.back() == (uint32_t)i) runs.back() = (uint32_t)i + 1;       // extends the open run
-                        else { runs.push_back((uint32_t)i); runs.push_back((uint32_t)i + 1); }
-                    }
-                }
-            }
-            const uint64_t sites = (runs.size() - first) / 2;
-            if (sites > 4u + (uint64_t)lens[g] * 160u / 1048576u * (uint64_t)c->exc_limit / 128u) {
-                runs.resize(first);                                   // too many: the byte kernel serves this one
-                c->is_packed[g] = 0;
-                continue;
-            }
-            roff[g] = (uint32_t)(first / 2);
+            if (!seq_ok[g]) { c->is_packed[g] = 0; continue; }
+            roff[g] = (uint32_t)(runs.size() / 2);
+            runs.insert(runs.end(), seq_runs[g].begin(), seq_runs[g].end());
             runs.push_back(0xFFFFFFFFu); runs.push_back(0xFFFFFFFFu);
             c->has_exc[g] = 1; c->any_exc = true; eoff[g] = foff[g];
-            c->any_other |= other;
+            c->any_other |= seq_other[g] != 0;
         }
     }
     c->up_ms[1] = up_lap();

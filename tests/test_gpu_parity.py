@@ -105,7 +105,9 @@ def test_mixed_alphabets_raw_blocks_and_n_runs(hip, oracle_mod):
             np.tile(o.lcg_genome(24, 700), 300),
             np.frombuffer(lcg_bytes(31, 90000, b"ACDEFGHIKLMNPQRSTVWY"), dtype=np.uint8),
             np.frombuffer(bytes(o.lcg_genome(25, 120000)).lower(), dtype=np.uint8)]
-    assert _check_all(hip, oracle_mod, seqs) == 3            # the genome with one N run stays on the 2-bit kernel (an exception site)
+    # the genome with one N run stays on the 2-bit kernel (an exception site), and so does (round 4) the lower-case genome of this
+    # upper-case set: one stretch of the other case, however long
+    assert _check_all(hip, oracle_mod, seqs) == 4
     assert _check_all(hip, oracle_mod, seqs, exc_limit=0) == 2
     _check_all(hip, oracle_mod, seqs, bytes_legacy=1)
 
@@ -530,7 +532,8 @@ def test_lower_case_sets_run_on_the_2bit_kernel(hip, oracle_mod):
         ctx.upload(lower)
         assert ctx.num_packed == len(lower)               # all five on the 2-bit kernel
         ctx.upload(lower[:2] + [g[4]])
-        assert ctx.num_packed == 2                        # the upper-case genome of a lower-case set takes the byte kernel
+        assert ctx.num_packed == 3                        # (round 4) the upper-case genome of a lower-case set stays on the 2-bit kernel too: one long
+                                                          # stretch of the other case, walked in the steady loop's other-case mode
 
 
 def test_related_genomes_same_ancestor(hip, oracle_mod):
