@@ -86,7 +86,7 @@ struct snk_ctx_impl {
     uint32_t *d_exc_flags = nullptr, *d_exc_off = nullptr, *d_ovf = nullptr; size_t ovf_bytes = 0;
     uint32_t *d_exc_runs = nullptr, *d_exc_roff = nullptr;
     uint16_t *d_lut_h2s = nullptr, *d_lut_s2h = nullptr, *d_lut_okey = nullptr;
-    uint16_t *d_lut_oj = nullptr; uint32_t *d_lut_omap = nullptr;     // the other-case mode's compact slots (snk_oth_swap_in)
+    uint16_t *d_lut_oj = nullptr, *d_lut_ovi = nullptr; uint32_t *d_lut_omap = nullptr;     // the other-case mode's compact slots (snk_oth_swap_in)
     uint32_t *d_osave = nullptr;                                      // ... and its save areas, one per resident chain (beside d_ovf)
     // deflate add-on (snk_deflate.hip): opaque state + its destructor
     void *dfl = nullptr; void (*dfl_free)(void *) = nullptr;
@@ -279,17 +279,26 @@ int upload_luts(snk_ctx_impl *c)
     if (!build_luts(slot, hash, c->lower)) return fail(c, SNK_E_STATE, "5-mer slot count exceeds the table");
     std::vector<uint16_t> h2s(4096, 0xFFFF), s2h(SNK_FSLOTS, 0);       // hash <-> slot (general path of sequences with exceptions)
     for (uint32_t k = 0; k < 1024; ++k) { h2s[hash[k]] = slot[k]; s2h[slot[k]] = (uint16_t)hash[k]; }
-    {   // the other case's 5-mers: shared slot, or liblz4's own hash for the overflow table
+    {   // the other case's 5-mers: their own compact numbering (oslot: code -> j), which is also where their hashes sit in a chain's
+        // overflow table (ovi: hash -> index; the other hashes follow); shared slot, or the overflow index, for the general path
         std::vector<uint16_t> oslot; std::vector<uint32_t> ohash;
         build_luts(oslot, ohash, !c->lower);
+        std::vector<uint16_t> ovi(4096, 0xFFFF);
+        uint32_t n_o = 0;
+        for (uint32_t k = 0; k < 1024; ++k) { ovi[ohash[k]] = oslot[k]; n_o = std::max<uint32_t>(n_o, oslot[k] + 1u); }
+        for (uint32_t h = 0; h < 4096; ++h) if (ovi[h] == 0xFFFF) ovi[h] = (uint16_t)n_o++;
         std::vector<uint16_t> okey(1024);
-        for (uint32_t k = 0; k < 1024; ++k) okey[k] = h2s[ohash[k]] != 0xFFFF ? h2s[ohash[k]] : (uint16_t)(0x1000u | ohash[k]);
-        HIPCHK(c, hipMemcpy(c->d_lut_okey, okey.data(), 2048, hipMemcpyHostToDevice));
-        // the other case's own numbering (the other-case mode keeps its table in LDS): oslot is code -> compact slot already
         std::vector<uint32_t> omap(SNK_FSLOTS, 0xFFFF0000u);
-        for (uint32_t k = 0; k < 1024; ++k) omap[oslot[k]] = ohash[k] | ((uint32_t)h2s[ohash[k]] << 16);
+        for (uint32_t k = 0; k < 1024; ++k) {
+            const bool shared = h2s[ohash[k]] != 0xFFFF;
+            okey[k] = shared ? h2s[ohash[k]] : (uint16_t)(0x1000u | oslot[k]);
+            omap[oslot[k]] = ohash[k] | ((uint32_t)h2s[ohash[k]] << 16);
+        }
+        for (uint32_t h = 0; h < 4096; ++h) if (h2s[h] == 0xFFFF) h2s[h] = (uint16_t)(0x8000u | ovi[h]);      // (after its use as "shared?" above)
+        HIPCHK(c, hipMemcpy(c->d_lut_okey, okey.data(), 2048, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_lut_oj, oslot.data(), 2048, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_lut_omap, omap.data(), SNK_FSLOTS * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_lut_ovi, ovi.data(), 8192, hipMemcpyHostToDevice));
     }
     HIPCHK(c, hipMemcpy(c->d_lut_h2s, h2s.data(), 8192, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_lut_s2h, s2h.data(), SNK_FSLOTS * 2, hipMemcpyHostToDevice));
@@ -306,7 +315,7 @@ SnkTables make_tables(const snk_ctx_impl *c)
     T.snap_fast = c->d_snap_fast; T.snap_gen = c->d_snap_gen;
     T.exc_runs = c->d_exc_runs; T.exc_roff = c->d_exc_roff;
     T.exc_flags = c->d_exc_flags; T.exc_off = c->d_exc_off; T.lut_h2s = c->d_lut_h2s; T.lut_s2h = c->d_lut_s2h; T.lut_okey = c->d_lut_okey; T.ovf = c->d_ovf;
-    T.lut_oj = c->d_lut_oj; T.lut_omap = c->d_lut_omap; T.osave = c->d_osave;
+    T.lut_oj = c->d_lut_oj; T.lut_omap = c->d_lut_omap; T.lut_ovi = c->d_lut_ovi; T.osave = c->d_osave;
     T.slots = c->d_slots; T.lut_slot = c->d_lut_slot; T.lut_h2c = c->d_lut_h2c; T.lut_h2c4 = c->d_lut_h2c4; T.zero_pad = c->d_zero; T.header_bytes = c->header_bytes;
     return T;
 }
@@ -785,6 +794,7 @@ int snk_ctx_create(int device, snk_ctx **out)
         CRCHK(hipMalloc((void **)&c->d_lut_s2h, SNK_FSLOTS * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_okey, 1024 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_oj, 1024 * sizeof(uint16_t)));
+        CRCHK(hipMalloc((void **)&c->d_lut_ovi, 4096 * sizeof(uint16_t)));
         CRCHK(hipMalloc((void **)&c->d_lut_omap, SNK_FSLOTS * sizeof(uint32_t)));
         if (upload_luts(c) != SNK_OK) { snk_ctx_destroy(c); return SNK_E_STATE; }
     }
@@ -799,7 +809,7 @@ void snk_ctx_destroy(snk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_sequences(c);
-    dfree(c->d_lut_h2s); dfree(c->d_lut_s2h); dfree(c->d_lut_okey); dfree(c->d_lut_oj); dfree(c->d_lut_omap);
+    dfree(c->d_lut_h2s); dfree(c->d_lut_s2h); dfree(c->d_lut_okey); dfree(c->d_lut_oj); dfree(c->d_lut_ovi); dfree(c->d_lut_omap);
     dfree(c->d_zero); dfree(c->d_lut_slot); dfree(c->d_lut_hash); dfree(c->d_lut_h2c); dfree(c->d_lut_h2c4); dfree(c->d_hashset); dfree(c->d_status);
     dfree(c->d_jobs); dfree(c->d_out);
     for (auto &e : c->ev_log) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -83,16 +83,20 @@ struct SnkTables {
     const uint32_t *exc_runs;         // exact runs of non-ACGT bytes, {start, end} pairs sorted by position, each sequence's
                                       // list ends with {0xFFFFFFFF, 0xFFFFFFFF}
     const uint32_t *exc_roff;         // per sequence: index of its first pair in exc_runs (only read when exc_off says it has some)
-    const uint16_t *lut_h2s;          // [4096] liblz4 hash of 5 bytes -> slot of the 2-bit table, 0xFFFF = no ACGT 5-mer has it
+    const uint16_t *lut_h2s;          // [4096] liblz4 hash of 5 bytes -> slot of the 2-bit table (< 0x8000), or 0x8000 | index of the hash in
+                                      //        the chain's overflow table (no 5-mer of the set's case has it)
+    const uint16_t *lut_ovi;          // [4096] liblz4 hash -> its index in an overflow table: the hashes of the other case's 5-mers come
+                                      //        first, by their compact numbers (lut_oj), then all the others
     const uint16_t *lut_s2h;          // [896]  slot -> hash
     const uint16_t *lut_okey;         // [1024] 5-mer code -> where liblz4 keeps the 5-mer written in the OTHER case: the slot of the
-                                      // 2-bit table (< 896) when a 5-mer of the set's case has the same hash, else 0x1000 | hash (ovf)
+                                      // 2-bit table (< 896) when a 5-mer of the set's case has the same hash, else 0x1000 | index in ovf
     uint32_t       *ovf;              // [resident chains][4096] overflow tables (absolute positions, liblz4's own layout)
     // the other-case mode on a table in LDS (round 4, snk_oth_swap_in / _out): the liblz4 hashes of the 1024 other-case 5-mers
     // numbered 0 .. 894 ("compact other-case slots")
     const uint16_t *lut_oj;           // [1024] 5-mer code -> compact other-case slot (the kernels keep a copy at LDS offset 2048)
-    const uint32_t *lut_omap;         // [896]  compact other-case slot -> liblz4 hash | (slot of the 2-bit table when a 5-mer of the
-                                      //        set's case has the same hash, else 0xFFFF) << 16; entry 895 unused
+    const uint32_t *lut_omap;         // [896]  compact other-case slot j -> liblz4 hash | (slot of the 2-bit table when a 5-mer of the
+                                      //        set's case has the same hash, else 0xFFFF) << 16; entry 895 unused.  Entry j of a chain's
+                                      //        overflow table belongs to the same hash
     uint32_t       *osave;            // [resident chains][512] where a chain's set-case table waits while its LDS region holds the other case's
     uint32_t        header_bytes;     // 7, or 15 with the content-size field
 };

@@ -231,13 +231,13 @@ __device__ __forceinline__ uint32_t snk_exc_next(SnkFastLane &L, uint32_t p)
 
 __device__ __forceinline__ void snk_exc_put(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm, uint32_t h, uint32_t pos)
 {
-    const uint32_t s = T.lut_h2s[h];
-    if (s != 0xFFFFu) {
+    const uint32_t s = T.lut_h2s[h];                                // < 0x8000: slot of the 2-bit table; else 0x8000 | index in the overflow table
+    if (s < 0x8000u) {
         tbl[s] = (uint16_t)(pos - L.base);                          // (<= 65 527: puts end 12 bytes before the block does)
         atomicOr(&bm[s >> 5], 1u << (s & 31u));
     } else {
         SNK_COUNT_HEAVY(7);
-        L.ovf[h] = pos;
+        L.ovf[s & 0xFFFu] = pos;
     }
 }
 
@@ -245,13 +245,13 @@ __device__ __forceinline__ uint32_t snk_exc_get(const SnkFastLane &L, const SnkT
                                                 uint32_t h, uint32_t cur, bool &valid)
 {
     const uint32_t s = T.lut_h2s[h];
-    if (s != 0xFFFFu) {
+    if (s < 0x8000u) {
         const uint32_t e = tbl[s];
         const bool iscur = ((bm[s >> 5] >> (s & 31u)) & 1u) != 0u;
         valid = iscur | (e > cur - L.base);
         return L.base + e - (iscur ? 0u : 65536u);
     }
-    const uint32_t cand = L.ovf[h];
+    const uint32_t cand = L.ovf[s & 0xFFFu];
     valid = cand + SNK_MAXDIST >= cur;
     return cand;
 }
@@ -487,7 +487,7 @@ __device__ __forceinline__ void snk_oth_swap_in_all(const SnkTables &T, uint8_t 
     {
         const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(tm), flut, wave, lanes, chain0, my_base);
 #pragma unroll
-        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) pc[i] = c.ov[om[i] & 0xFFFu];
+        for (uint32_t i = 0; i < SNK_OTH_NPL; ++i) pc[i] = c.ov[lane + SNK_OTH_STR * i];          // (entry j of the overflow table: coalesced)
     }
     for (unsigned long long t2 = tm; t2; t2 &= t2 - 1ull) {
         const SnkOthChain c = snk_oth_chain<SPEC>(T, lds, (uint32_t)__builtin_ctzll(t2), flut, wave, lanes, chain0, my_base);
@@ -504,7 +504,7 @@ __device__ __forceinline__ void snk_oth_swap_in_all(const SnkTables &T, uint8_t 
             const uint32_t vs = tb[sx] | (((bmw[sx >> 5] >> (sx & 31u)) & 1u) << 16);
             const int32_t rel = (int32_t)(pc[i] - c.base);                             // absolute position -> the table's form
             const uint32_t vo = rel >= 0 ? ((uint32_t)rel | 0x10000u) : rel >= -65536 ? (uint32_t)(rel + 65536) : 0u;
-            pc[i] = n.ov[om[i] & 0xFFFu];                                              // the next chain's entry (the last chain: its own again)
+            pc[i] = n.ov[j];                                                           // the next chain's entry (the last chain: its own again)
             val[i] = j < SNK_OTH_SLOTS ? (sl != 0xFFFFu ? vs : vo) : 0u;
         }
         for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_OTH_STR) bmw[t] = 0u;      // (after every read of the old table)
@@ -552,7 +552,7 @@ __device__ __forceinline__ void snk_oth_swap_out_all(const SnkTables &T, uint8_t
                 v = e | (b << 16);
                 // (an entry that is neither of this block nor in reach from it is dead for good: positions only grow.  Dead entries are
                 // zeroed at block ends from the third block on, where position 0 is out of reach too -- so 0 says the same)
-                if ((om[i] >> 16) == 0xFFFFu) c.ov[om[i] & 0xFFFu] = b ? c.base + e : (e ? c.base - 65536u + e : 0u);
+                if ((om[i] >> 16) == 0xFFFFu) c.ov[j] = b ? c.base + e : (e ? c.base - 65536u + e : 0u);
             }
             val[i] = v;
         }
@@ -602,7 +602,7 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
                 uint32_t *gen = T.snap_gen + (size_t)L.xi * 4096u;
                 for (uint32_t h = 0; h < 4096u; ++h) {
                     const uint32_t sl = T.lut_h2s[h];
-                    gen[h] = sl != 0xFFFFu ? dst[sl] : L.ovf[h];
+                    gen[h] = sl < 0x8000u ? dst[sl] : L.ovf[sl & 0xFFFu];
                 }
             }
             T.snap_out[L.xi] = L.total;
@@ -2170,7 +2170,9 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 if (EXC) {
                     uint32_t *ov = T.ovf + ((size_t)(blockIdx.x * waves + wave) * lanes + lc) * 4096u;
                     const uint32_t *gsrc = T.snap_gen + (size_t)xi * 4096u;
-                    for (uint32_t t = lane; t < 4096u; t += SNK_COOP(64u)) ov[t] = use ? gsrc[t] : 0u;
+                    // (the overflow table is indexed through lut_ovi: the other case's hashes first, by their compact numbers --
+                    // what the table swaps of the other-case mode read and write with coalesced accesses)
+                    for (uint32_t t = lane; t < 4096u; t += SNK_COOP(64u)) ov[T.lut_ovi[t]] = use ? gsrc[t] : 0u;
                 }
                 // no snapshot: position 0 counts as "written in this block"
                 for (uint32_t t = lane; t < SNK_FBMWORDS; t += SNK_COOP(64u)) ((uint32_t *)(dst + SNK_FSLOTS * 2u))[t] = use ? 0u : 0xFFFFFFFFu;

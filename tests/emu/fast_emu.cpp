@@ -54,30 +54,31 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
         }
         if (n_slots >= (int)SNK_FSLOTS) return -1;         // (the last slot stays free: "nothing owed" puts go there)
     }
-    std::vector<uint16_t> okey(1024, 0);               // the other case's 5-mers: shared slot, or 0x1000 | liblz4's hash
-    for (uint32_t k = 0; k < 1024; ++k) {
-        uint8_t b[5];
-        for (int i = 0; i < 5; ++i) b[i] = (uint8_t)(code2byte[(k >> (2 * i)) & 3] ^ 0x20);
-        const uint32_t h = host_hash5(b);
-        okey[k] = h2s[h] != 0xFFFF ? h2s[h] : (uint16_t)(0x1000u | h);
-    }
-    // the other case's own numbering of its hashes (the other-case mode keeps its table in LDS: snk_oth_swap_in), and both LUTs
-    // back to back as the kernels for sequences with exceptions hold them in LDS
-    std::vector<uint16_t> oj(1024, 0), luts(2048, 0);
+    // the other case's 5-mers: their own compact numbering (oj: code -> j; the other-case mode keeps its table in LDS:
+    // snk_oth_swap_in), which is also where their hashes sit in a chain's overflow table (ovi: hash -> index; the other hashes
+    // follow); okey: shared slot of the 2-bit table, or 0x1000 | overflow index, for the general path; both LUTs back to back as
+    // the kernels for sequences with exceptions hold them in LDS
+    std::vector<uint16_t> okey(1024, 0), oj(1024, 0), ovi(4096, 0xFFFF);
     std::vector<uint32_t> omap(SNK_FSLOTS, 0xFFFF0000u);
     {
-        std::vector<int> cls(4096, -1);
-        int ncls = 0;
+        std::vector<uint32_t> oh(1024);
+        uint32_t ncls = 0;
         for (uint32_t k = 0; k < 1024; ++k) {
             uint8_t b[5];
             for (int i = 0; i < 5; ++i) b[i] = (uint8_t)(code2byte[(k >> (2 * i)) & 3] ^ 0x20);
             const uint32_t h = host_hash5(b);
-            if (cls[h] < 0) cls[h] = ncls++;
-            oj[k] = (uint16_t)cls[h];
-            omap[(size_t)cls[h]] = h | ((uint32_t)h2s[h] << 16);
+            oh[k] = h;
+            if (ovi[h] == 0xFFFF) ovi[h] = (uint16_t)ncls++;
+            oj[k] = ovi[h];
         }
-        if (ncls >= (int)SNK_FSLOTS) return -1;
-        for (uint32_t k = 0; k < 1024; ++k) { luts[k] = slot[k]; luts[1024 + k] = oj[k]; }
+        if (ncls >= SNK_FSLOTS) return -1;
+        for (uint32_t h = 0; h < 4096; ++h) if (ovi[h] == 0xFFFF) ovi[h] = (uint16_t)ncls++;
+        for (uint32_t k = 0; k < 1024; ++k) {
+            const bool shared = h2s[oh[k]] != 0xFFFF;
+            okey[k] = shared ? h2s[oh[k]] : (uint16_t)(0x1000u | oj[k]);
+            omap[oj[k]] = oh[k] | ((uint32_t)h2s[oh[k]] << 16);
+        }
+        for (uint32_t h = 0; h < 4096; ++h) if (h2s[h] == 0xFFFF) h2s[h] = (uint16_t)(0x8000u | ovi[h]);
     }
     std::vector<uint8_t> ok((size_t)n, 0), exc((size_t)n, 0);
     std::vector<uint32_t> poff((size_t)n, 0), boff((size_t)n, 0), len((size_t)n), spos((size_t)n), eoff((size_t)n, 0xFFFFFFFFu);
@@ -150,7 +151,7 @@ extern "C" int emu_fast_sizes(int n, const uint8_t *const *seqs, const uint64_t 
     T.packed_arena = arena.data(); T.mask_arena = marena.data(); T.packed_off = poff.data(); T.len = len.data();
     T.bytes_arena = bytes.data(); T.bytes_off = boff.data(); T.zero_pad = zero.data();
     T.snap_pos = spos.data(); T.snap_out = snap_out.data(); T.snap_fast = snap_fast.data(); T.snap_gen = snap_gen.data();
-    T.lut_oj = oj.data(); T.lut_omap = omap.data(); T.osave = osave.data();
+    T.lut_oj = oj.data(); T.lut_omap = omap.data(); T.lut_ovi = ovi.data(); T.osave = osave.data();
     T.lut_slot = slot.data(); T.lut_h2s = h2s.data(); T.lut_s2h = s2h.data(); T.lut_okey = okey.data(); T.header_bytes = header_bytes;
     T.exc_flags = fl.data(); T.exc_off = eoff.data(); T.ovf = ovf.data(); T.exc_runs = runs.data(); T.exc_roff = roff.data();
 
