@@ -206,6 +206,8 @@ def secondary_leg(name, genomes, codec, local_rank, dev, R, steps, opts, data_ke
         ctx.upload(genomes)
         if deflate:
             ctx.deflate_singles(codec)
+        elif R == 84:
+            R = ctx.fast_chains()                      # (a set with other-case letters holds 83 chains per CU: its rows per step follow)
         t_setup = time.perf_counter() - t0
         stream = torch.cuda.Stream(dev)
         tile = torch.zeros((R, N), dtype=torch.int32, device=dev)

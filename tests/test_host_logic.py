@@ -340,7 +340,12 @@ def test_bench_reads_the_committed_profile_summaries():
     assert bench.pmc_traffic(84, 1024, 1000000, "lz4")[1].startswith("profiles/r03_pmc_traffic.json @ ")
     assert "?" not in bench.pmc_traffic(84, 1024, 1000000, "lz4")[1]                  # names its commit
     assert bench.pmc_traffic(84, 1000, 1000000)[0] is None           # another launch shape: no figure
-    assert bench.pmc_traffic(84, 1024, 1000000, "lz4", "markov")[0] is None   # another data set: no figure
+    # (round 4) the secondary data sets have counters of their own; a set measured on another launch shape has no figure
+    tm, srcm = bench.pmc_traffic(84, 1024, 1000000, "lz4", "markov")
+    assert tm and tm > 0 and srcm.startswith("profiles/r04_pmc_traffic_markov.json @ ")
+    assert bench.pmc_traffic(84, 1024, 1000000, "lz4", "softmask5")[0] is None     # (taken at 83 rows: sets with other-case letters hold 83 chains)
+    assert bench.pmc_traffic(83, 1024, 1000000, "lz4", "softmask5")[0] > 0
+    assert bench.pmc_traffic(84, 1024, 1000000, "lz4", "no-such-set")[0] is None
     im = bench.issue_model()
     # (the two-lane loop of round 3: ~134 issue slots per chain-trip, 1.66 probes per chain-trip)
     assert 60 < im["issue_slots_per_trip"] < 160 and im["measured_cycles_per_trip"] > im["issue_slots_per_trip"] * 4
