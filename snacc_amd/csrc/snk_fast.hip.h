@@ -1557,7 +1557,25 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "s_cbranch_vccz 1b\n\t" \
     SNK_SPEC_OPN \
     "s_waitcnt lgkmcnt(0)\n\t"
-#define SNK_SPEC_OPERANDS \
+// The two-lane loop's VGPR operands are PINNED (round 4).  Which registers the compiler gives the operands decides ~2 % of the
+// kernel's rate (VGPR banks of the VALU's source operands: round 3 saw it when early-clobber constraints renumbered them), and
+// the allocator's choice moves with any edit of the code AROUND the loop: by the end of round 4's work on the exception
+// kernels the same loop ran at 560 k instead of 572 k pair-compr./s (A/B on one box against the round-3 build, interleaved).
+// These are the registers the round-3 build gave the loop of blocks past the seam (the form the y walk runs) -- 572 k again,
+// whatever the surroundings do from here on.  (SGPR operands are left to the allocator: scalar operands have no banks.)
+#define SNK_SPEC_OPERANDS SNK_SPEC_OPERANDS_PIN SNK_SPEC_CLOBBERS
+// (the kernels for sequences with exceptions keep the allocator's choice: their loop sits among 250 live registers)
+#define SNK_SPEC_OPERANDS_X SNK_SPEC_OPERANDS_FREE SNK_SPEC_CLOBBERS
+#define SNK_SPEC_OPERANDS_PIN \
+    : [c] "+{v4}"(c), [wc] "+{v81}"(wc), [s1] "+{v82}"(s1), [s2] "+{v85}"(s2), [r0] "+{v24}"(r0), [r1] "+{v25}"(r1), \
+      [rbc] "+{v84}"(rbc), [nxoff] "+{v23}"(nxoff), [anchor] "+{v78}"(anchor_c), [op] "+{v73}"(op), \
+      [opn] "+{v86}"(opn), [ns2] "+{v83}"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), [sq] "+s"(sq), [sc] "+s"(sc), \
+      [t] "=&{v22}"(t), [lit] "=&{v87}"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sp] "=&s"(sp), \
+      [sb] "=&s"(sb), [ex] "=&s"(ex) \
+    : [lb] "{v34}"(lds_off), [five] "{v29}"(five), [fivec] "{v31}"(5u - five), [sx] "{v76}"(sx), [kx] "{v74}"(kx), \
+      [xoffB] "{v77}"(xoffB), [yoffB] "{v80}"(yoffB), [T0] "{v20}"(T0), [limc] "{v79}"(limc), [oz] "{v75}"(oz), [dm] "{v28}"(DUMMY), \
+      [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "{v5}"(0u)
+#define SNK_SPEC_OPERANDS_FREE \
     : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
       [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
       [opn] "+v"(opn), [ns2] "+v"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), [sq] "+s"(sq), [sc] "+s"(sc), \
@@ -1565,7 +1583,8 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
       [sb] "=&s"(sb), [ex] "=&s"(ex) \
     : [lb] "v"(lds_off), [five] "v"(five), [fivec] "v"(5u - five), [sx] "v"(sx), [kx] "v"(kx), \
       [xoffB] "v"(xoffB), [yoffB] "v"(yoffB), [T0] "v"(T0), [limc] "v"(limc), [oz] "v"(oz), [dm] "v"(DUMMY), \
-      [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "v"(0u) \
+      [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "v"(0u)
+#define SNK_SPEC_CLOBBERS \
     : "memory", "vcc", "scc", "v88", "v89", \
       "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
       "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
@@ -1656,20 +1675,27 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
         uint32_t opn = op, lit;
         if (R1) op = 0u, opn = 0u;                                              // role 1 keeps no account
         uint64_t sm = __builtin_amdgcn_ballot_w64(R1 || pend0), sl = 0, scm = 0, sc0 = 0, sq = 0, sc = 0, sv, ss, st, sp, sb, ex;   // (sq, sc: nothing to commit in the first trip)
-        if (!EXC || !need_mask) {
+        if (!EXC) {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
                              SNK_SPEC_OPERANDS);
             else
                 asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW("v103") SNK_STEADY_STRADDLE
                              SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST("v105") SNK_SPEC_OPERANDS);
+        } else if (!need_mask) {
+            if (__all(sx + 15 <= 0))
+                asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW("%[t]") SNK_SPEC_PRE("") SNK_SPEC_REST("%[limc]")
+                             SNK_SPEC_OPERANDS_X);
+            else
+                asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW("v103") SNK_STEADY_STRADDLE
+                             SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST("v105") SNK_SPEC_OPERANDS_X);
         } else {
             if (__all(sx + 15 <= 0))
                 asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_YONLY SNK_SPEC_SHADOW_X("%[t]", SNK_SPEC_MASKLOAD) SNK_SPEC_PRE("")
-                             SNK_SPEC_REST_X("%[limc]", SNK_SPEC_MASKOR, "1") SNK_SPEC_OPERANDS);
+                             SNK_SPEC_REST_X("%[limc]", SNK_SPEC_MASKOR, "1") SNK_SPEC_OPERANDS_X);
             else
                 asm volatile(SNK_SPEC_TABLE SNK_STEADY_ADDR_DUAL SNK_SPEC_SHADOW_X("v103", SNK_SPEC_MASKLOAD) SNK_STEADY_STRADDLE
-                             SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST_X("v105", SNK_SPEC_MASKOR, "1") SNK_SPEC_OPERANDS);
+                             SNK_SPEC_PRE("s_or_b64 %[sp], %[sp], %[ss]\n\t") SNK_SPEC_REST_X("v105", SNK_SPEC_MASKOR, "1") SNK_SPEC_OPERANDS_X);
         }
 #ifdef SNK_STATS
         const unsigned long long stat_t1 = clock64();
