@@ -875,6 +875,19 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 #define SNK_CONTRACT_BLK
 #define SNK_OPERAND_BLK
 #endif
+// The head of every hand-scheduled loop sits on a 64-byte boundary (one instruction-cache line).  Left where it falls, the
+// two-lane loop's rate moves by 2.3 % with whatever the code in front of it happens to measure: heads at 24 or 56 bytes past
+// a 64-byte boundary are the slow ones, the six other multiples of 8 run alike.
+// -DSNK_LOOP_P2ALIGN=0 builds the loops where they fall, -DSNK_LOOP_PADN=n puts n s_nop words behind the boundary (the sweep).
+#ifndef SNK_LOOP_P2ALIGN
+#define SNK_LOOP_P2ALIGN 6
+#endif
+#define SNK_LOOP_STR2(x) #x
+#define SNK_LOOP_STR(x) SNK_LOOP_STR2(x)
+#ifndef SNK_LOOP_PADN
+#define SNK_LOOP_PADN 0
+#endif
+#define SNK_LOOP_ALIGN ".p2align " SNK_LOOP_STR(SNK_LOOP_P2ALIGN) "\n\t.fill " SNK_LOOP_STR(SNK_LOOP_PADN) ", 4, 0xbf800000\n\t"
 #define SNK_STEADY_CONTRACT \
     "; snk-asm-contract inout %[c] %[wc] %[s1] %[s2] %[r0] %[r1] %[rbc] %[nxoff] %[anchor] %[op] %[opn] %[ns2] %[sm] %[sl]" \
     " | in %[lb] %[sx] %[kx] %[xoffB] %[yoffB] %[T0] %[limc] %[oz] %[dm] %[k8] %[arena] %[marena]" SNK_CONTRACT_BLK "\n\t"
@@ -885,6 +898,7 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 // (the other-case mode parks lanes inside the loop -- see SNK_STEADY_PARK_OTH -- and restores EXEC when it leaves)
 #define SNK_STEADY_TABLE_OTH SNK_STEADY_CONTRACT "s_mov_b64 %[se], exec\n\t" SNK_STEADY_TABLE_BODY
 #define SNK_STEADY_TABLE_BODY \
+    SNK_LOOP_ALIGN \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur (the slot of cur-2 may still be in flight) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
@@ -921,6 +935,7 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 #define SNK_STEADY_TABLE_FAR \
     SNK_STEADY_CONTRACT_FAR \
     SNK_STEADY_ENTER \
+    SNK_LOOP_ALIGN \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t"                          /* slot of cur */ \
     "v_lshl_add_u32 v90, %[s1], 2, %[gtb]\n\t" \
@@ -1419,6 +1434,7 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     SNK_SPEC_CONTRACT \
     "s_mov_b64 %[ex], exec\n\t"                         /* the lanes of the loop */ \
     SNK_SPEC_CURS \
+    SNK_LOOP_ALIGN \
     "1:\n\t" \
     "s_waitcnt lgkmcnt(" SNK_SPEC_W0 ")\n\t"            /* the slots of cur and cur-2 (behind them: role 1's four put operations) */ \
     "v_lshl_add_u32 v90, %[s1], 1, %[lb]\n\t" \
@@ -1557,24 +1573,13 @@ __device__ __forceinline__ void snk_fast_steady(SnkFastLane &L, snk_g8 *const ar
     "s_cbranch_vccz 1b\n\t" \
     SNK_SPEC_OPN \
     "s_waitcnt lgkmcnt(0)\n\t"
-// The two-lane loop's VGPR operands are PINNED (round 4).  Which registers the compiler gives the operands decides ~2 % of the
-// kernel's rate (VGPR banks of the VALU's source operands: round 3 saw it when early-clobber constraints renumbered them), and
-// the allocator's choice moves with any edit of the code AROUND the loop: by the end of round 4's work on the exception
-// kernels the same loop ran at 560 k instead of 572 k pair-compr./s (A/B on one box against the round-3 build, interleaved).
-// These are the registers the round-3 build gave the loop of blocks past the seam (the form the y walk runs) -- 572 k again,
-// whatever the surroundings do from here on.  (SGPR operands are left to the allocator: scalar operands have no banks.)
-#define SNK_SPEC_OPERANDS SNK_SPEC_OPERANDS_PIN SNK_SPEC_CLOBBERS
-// (the kernels for sequences with exceptions keep the allocator's choice: their loop sits among 250 live registers)
+// (Round 4 pinned these VGPR operands for a while: the loop had drifted from 572 k to 560 k pair-compr./s as the code around
+// it changed, and giving the operands the round-3 build's registers brought the rate back.  The cause was not the registers
+// but WHERE THE LOOP LAY: with its head 24 bytes past a 32-byte boundary the same instructions run 2.3 % slower -- a sweep of
+// the head's offset in steps of 8 bytes, DESIGN.md section 6.00 -- and either allocation runs at 572 k once the head is
+// aligned, SNK_LOOP_ALIGN.  So the allocator keeps the choice.)
+#define SNK_SPEC_OPERANDS SNK_SPEC_OPERANDS_FREE SNK_SPEC_CLOBBERS
 #define SNK_SPEC_OPERANDS_X SNK_SPEC_OPERANDS_FREE SNK_SPEC_CLOBBERS
-#define SNK_SPEC_OPERANDS_PIN \
-    : [c] "+{v4}"(c), [wc] "+{v81}"(wc), [s1] "+{v82}"(s1), [s2] "+{v85}"(s2), [r0] "+{v24}"(r0), [r1] "+{v25}"(r1), \
-      [rbc] "+{v84}"(rbc), [nxoff] "+{v23}"(nxoff), [anchor] "+{v78}"(anchor_c), [op] "+{v73}"(op), \
-      [opn] "+{v86}"(opn), [ns2] "+{v83}"(ns2), [sm] "+s"(sm), [sl] "+s"(sl), [scm] "+s"(scm), [sc0] "+s"(sc0), [sq] "+s"(sq), [sc] "+s"(sc), \
-      [t] "=&{v22}"(t), [lit] "=&{v87}"(lit), [sv] "=&s"(sv), [ss] "=&s"(ss), [st] "=&s"(st), [sp] "=&s"(sp), \
-      [sb] "=&s"(sb), [ex] "=&s"(ex) \
-    : [lb] "{v34}"(lds_off), [five] "{v29}"(five), [fivec] "{v31}"(5u - five), [sx] "{v76}"(sx), [kx] "{v74}"(kx), \
-      [xoffB] "{v77}"(xoffB), [yoffB] "{v80}"(yoffB), [T0] "{v20}"(T0), [limc] "{v79}"(limc), [oz] "{v75}"(oz), [dm] "{v28}"(DUMMY), \
-      [k8] "s"(0x00800000u), [arena] "s"(arena), [marena] "s"(marena), [r1m] "s"(r1m), [vz] "{v5}"(0u)
 #define SNK_SPEC_OPERANDS_FREE \
     : [c] "+v"(c), [wc] "+v"(wc), [s1] "+v"(s1), [s2] "+v"(s2), [r0] "+v"(r0), [r1] "+v"(r1), \
       [rbc] "+v"(rbc), [nxoff] "+v"(nxoff), [anchor] "+v"(anchor_c), [op] "+v"(op), \
