@@ -136,7 +136,7 @@ __device__ unsigned long long snk_stats[64];      // [32..63]: the same account 
 #endif
 // the cycle account is kept in registers and added to snk_stats once, when the wave ends (atomics on the way would
 // change what they measure): every lane carries the same numbers, lane 0 reports them
-struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top, other, otrips, olanes, oin, oout; unsigned int entries, rounds, jobs, oruns, oswaps; };
+struct SnkProf { unsigned long long loop, finish, rounds_cyc, probe, prologue, top, other, otrips, olanes, oin, oout, be_cyc; unsigned int entries, rounds, jobs, oruns, oswaps, be_n, be_rounds; };
 #define SNK_PROF_ARG , SnkProf &P
 #define SNK_PROF_PASS , P
 #else
@@ -569,6 +569,7 @@ __device__ __forceinline__ void snk_oth_swap_out_all(const SnkTables &T, uint8_t
     }
 }
 
+struct alignas(16) SnkWord4 { uint32_t a, b, c, d; };
 // Rare path (once per 64 KiB): close the finished block, age the table, open the next block.
 // Returns true when the frame is complete (size written).
 // FAR (chains of the extra waves, see "Chains beyond the LDS" below): the table is gt[896], absolute positions as u32 in
@@ -577,6 +578,12 @@ template <bool EXC, bool FAR>
 __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTables &T, uint16_t *tbl, uint32_t *bm, uint32_t *gt,
                                                  const uint16_t *slot, uint32_t *out, uint32_t *status)
 {
+#if SNK_STATS + 0 >= 3
+    unsigned long long bs_ = clock64();
+#define SNK_BSTAMP(i) do { const unsigned long long n_ = clock64(); atomicAdd(&snk_stats[i], n_ - bs_); bs_ = n_; } while (0)
+#else
+#define SNK_BSTAMP(i) do { } while (0)
+#endif
     if (L.in_block) {
         uint32_t payload = L.blen;
         if (L.endcode != 2u) {
@@ -616,18 +623,54 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             L.pos = L.iend;
             continue;
         }
-        if (!FAR && !L.first) {
-            // age the table: entries not written during the block just finished are dead
-            for (uint32_t wi = 0; wi < SNK_FBMWORDS; ++wi) {
-                uint32_t z = ~bm[wi];
-                while (z) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(z);
-                    tbl[wi * 32u + b] = 0;
-                    z &= z - 1u;
-                }
-                bm[wi] = 0u;
+        SNK_BSTAMP(37);
+        // (pure ACGT chains) the reservoir of the new block's first cursor is seated HERE, its three loads in flight while the
+        // table is aged -- when that cursor reads the source the reservoir already reads (15 of a pair's 16 block ends lie inside
+        // y); the 5-mer of the block's first position then comes out of the reservoir too.  A block end cost the wave 7.4 k cycles
+        // between two loop entries where any other exit costs 2.8 k: 28 dependent LDS reads of the ageing, one global load for
+        // that 5-mer, and a further round for the re-seat (profiles/r04_cycle_account.json, block_end_passes).
+        bool seated = false;
+        if (!EXC && !FAR) {
+            const uint32_t ncur = L.pos + 1u, lx = L.s.lx;
+            if (ncur >= lx + 4u && L.w.org == lx && L.w.soff == L.s.yoff && L.w.lim == 0xFFFFFFFFu) {
+                snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, ncur); seated = true;
+            } else if (ncur >= 4u && ncur + 12u <= lx && L.w.org == 0u && L.w.soff == L.s.xoff && L.w.lim == lx - 12u) {
+                snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, ncur); seated = true;
             }
         }
+        if (!FAR && !L.first) {
+            // age the table: entries not written during the block just finished are dead.  (Four bitmap words per LDS read -- the
+            // chain's region is 16-byte aligned -- and, where the registers are there, all seven reads issued before the first is
+            // used: word by word this was 28 dependent LDS round trips.)
+            static_assert(SNK_FBMWORDS % 4u == 0u && SNK_FCHAIN_B % 16u == 0u && (SNK_FSLOTS * 2u) % 16u == 0u, "bitmap rows of 16 bytes");
+            constexpr uint32_t ROWS = SNK_FBMWORDS / 4u, RB = EXC ? 1u : ROWS;      // (the kernels for exceptions have no registers to spare)
+            // (With one wave per SIMD every instruction of this path costs the wave ~5 cycles, so the common case is made short:
+            // after a whole block nearly every slot has been written -- a row of 128 slots whose bits are all set costs three ANDs
+            // and a compare.)
+            for (uint32_t q0 = 0; q0 < ROWS; q0 += RB) {
+                SnkWord4 v[RB];
+#pragma unroll
+                for (uint32_t r = 0; r < RB; ++r) v[r] = *(const SnkWord4 *)(bm + 4u * (q0 + r));
+#pragma unroll
+                for (uint32_t r = 0; r < RB; ++r) {
+                    if ((v[r].a & v[r].b & v[r].c & v[r].d) == 0xFFFFFFFFu) continue;
+                    const uint32_t w4[4] = { v[r].a, v[r].b, v[r].c, v[r].d };
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        uint32_t z = ~w4[k];
+                        while (z) {
+                            const uint32_t b = (uint32_t)__builtin_ctz(z);
+                            tbl[(4u * (q0 + r) + k) * 32u + b] = 0;
+                            z &= z - 1u;
+                        }
+                    }
+                }
+                const SnkWord4 zero = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                for (uint32_t r = 0; r < RB; ++r) *(SnkWord4 *)(bm + 4u * (q0 + r)) = zero;
+            }
+        }
+        SNK_BSTAMP(38);
         L.first = false;
         L.base = L.pos - L.k3;
         L.mfl1 = L.iend - 11u; L.mlimit = L.iend - 5u; L.olimit = L.blen - 1u;
@@ -639,25 +682,38 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
             const uint32_t w0 = snk_fetch32(L.s, L.pos);
             gt[slot[(w0 >> 8) & 1023u]] = L.pos;
         } else {
-            const uint32_t w0 = snk_fetch32(L.s, L.pos);
-            const uint32_t s0 = slot[(w0 >> 8) & 1023u];
+            // the 5-mer at pos: bases pos - rb .. of the reservoir (rb = pos - 3 - ((pos - 3 - org) & 3): 3 .. 6 bases in)
+            const uint32_t k5 = seated ? __builtin_amdgcn_alignbit(L.w.r1, L.w.r0, 2u * (L.pos - L.w.rb)) & 1023u
+                                       : (snk_fetch32(L.s, L.pos) >> 8) & 1023u;
+            const uint32_t s0 = slot[k5];
             tbl[s0] = (uint16_t)L.k3;                                 // the block start, relative to the virtual base
             atomicOr(&bm[s0 >> 5], 1u << (s0 & 31u));
         }
         L.cur = L.pos + 1u; L.step = 1u; L.nb = 64u; L.anchor = L.pos; L.op = 0u;
         L.pending = false; L.in_block = true;
+        SNK_BSTAMP(39);
         return false;
     }
 }
 
 // Rare path of a match: long back-extension, long match, length-extension bytes, output
 // budget, end of block -- liblz4's exact accounting.
+// xb: the difference of the two windows' first four bases (cur-4 .. cur-1 against cand-4 .. cand-1, bits 0..7): the back-extension
+// starts on them -- no load for the usual 0..3 bases; every exit of the loop has a lane or two in here, and the loop's first
+// compare used to cost the wave a global round trip.
 __device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur, uint32_t cand, uint32_t f,
-                                                    uint32_t anchor0, uint32_t op0)
+                                                    uint32_t anchor0, uint32_t op0, uint32_t xb)
 {
     const SnkFastSrc &s = L.s;
     uint32_t ip = cur, lit = cur - anchor0;
-    while (ip > anchor0 && cand > 0u && snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
+    {
+        uint32_t k = (uint32_t)__builtin_clz((xb << 24) | 0x00800000u) >> 1;      // equal bases before the cursor inside the windows, 0..4
+        k = k < lit ? k : lit;
+        k = k < cand ? k : cand;
+        ip -= k; cand -= k; lit -= k;
+        if (k == 4u)
+            while (ip > anchor0 && cand > 0u && snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
+    }
     uint32_t e2 = cur + f;
     if (f == 12u) {                                          // keep counting, 16 bases at a time
         uint32_t bpos = cand + (cur - ip) + 12u;
@@ -696,7 +752,7 @@ __device__ __forceinline__ void snk_fast_finish(SnkFastLane &L, uint32_t cur, ui
     const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;          // equal bases from cur, 0..12
     SNK_TRACE_REC(6u, cur, cand, (f << 24) | (valid ? 0x400000u : 0u), cur);
     if (valid & (f >= 4u)) {
-        snk_fast_match_slow(L, cur, cand, f, L.anchor, L.op);
+        snk_fast_match_slow(L, cur, cand, f, L.anchor, L.op, x & 0xFFu);
     } else {
         const uint32_t s3 = L.nb >> 6;
         L.cur = cur + L.step; L.step = s3 ? s3 : 1u; L.nb += 1u; L.pending = false;
@@ -2097,7 +2153,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 
 #ifdef SNK_STATS
     const unsigned long long stat_w0 = clock64(), stat_wall0 = wall_clock64();      // (wall clock: constant 100 MHz -> the shader clock of the run)
-    SnkProf P = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0u, 0u, 0u, 0u, 0u };    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
+    SnkProf P = {};    // (lanes outside the loop's EXEC mask miss its share: lane 0 of a wave is
                                                                  //  nearly always inside -- good enough for an account)
 #endif
     // the chain of the wave this lane belongs to (TRI: rows of 16 lanes = 5 chains x 3 lanes, lane 15 idles), and its role in it
@@ -2131,6 +2187,8 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
     for (;;) {
 #ifdef SNK_STATS
         const unsigned long long stat_o0 = clock64();
+        const bool stat_be = __any(have && L.cur + L.step > L.mfl1);      // this pass between two loop entries serves a block end
+        const unsigned int stat_r0 = P.rounds;
 #endif
         // ---- hand jobs to the lanes that have none ----
         bool need = lane_on && !have;
@@ -2240,6 +2298,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 atomicAdd(&S[27], P.prologue); atomicAdd(&S[28], P.probe); atomicAdd(&S[29], P.top);
                 atomicAdd(&S[30], (unsigned long long)P.jobs); atomicAdd(&S[31], 1ull); atomicAdd(&S[23], P.other); atomicAdd(&S[48], P.otrips); atomicAdd(&S[49], P.olanes); atomicAdd(&S[50], (unsigned long long)P.oruns);
                 atomicAdd(&S[59], P.oin); atomicAdd(&S[60], P.oout); atomicAdd(&S[61], (unsigned long long)P.oswaps);
+                atomicAdd(&S[62], P.be_cyc); atomicAdd(&S[63], (unsigned long long)P.be_n); atomicAdd(&S[55], (unsigned long long)P.be_rounds);
             }
 #endif
             return;
@@ -2279,10 +2338,16 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 #ifdef SNK_STATS
         const unsigned long long stat_i0 = clock64();
         P.top += stat_i0 - stat_o0;                      // job hand-out, gathering at sites
+#if SNK_STATS + 0 >= 3
+        if (stat_be && lane == 0u) atomicAdd(&snk_stats[32], stat_i0 - stat_o0);
+#endif
 #endif
         for (;;) {
 #ifdef SNK_STATS
             P.rounds++;
+#if SNK_STATS + 0 >= 3
+            const unsigned long long stat_r_ = clock64();
+#endif
 #endif
             // Lanes of a wave share their suffix y (jobs are suffix-major) but reach it after x tails of
             // different lengths.  A lane that arrives parks until no lane of the wave is inside its x any
@@ -2349,13 +2414,30 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
             if (__builtin_expect(!__any(!ok), 1)) { flushing = false; break; }
 #ifdef SNK_STATS
             const unsigned long long stat_g0 = clock64();
+#if SNK_STATS + 0 >= 3
+            if (stat_be && lane == 0u) { atomicAdd(&snk_stats[33], stat_g0 - stat_r_); atomicAdd(&snk_stats[36], 1ull); }
+#endif
 #endif
             bool stat_done = false;
+            const bool edge = !ok && !oel && L.cur + L.step > L.mfl1;      // this lane closes a block / opens the next one in this round
             if (!ok && !oel && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; }   // frame complete
+            // (a block edge the block step has not seated the reservoir for -- the first block inside y, the seam --: seated here
+            // instead of in a round of its own)
+            if (!EXC && !FAR && edge && have && L.in_block && L.cur + L.step <= L.mfl1 && !snk_fast_eligible<EXC>(L)) {      // (else seated by the block step)
+                const uint32_t cur = L.cur, lx = L.s.lx;
+                if (cur >= lx + 4u) {
+                    if (L.w.org != lx && anyx) parked = true;                 // first time on y
+                    snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
+                } else if (cur >= 4u && cur + 12u <= lx)   snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
+            }
             (void)stat_done;
 #ifdef SNK_STATS
             P.jobs += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(stat_done));
             P.probe += clock64() - stat_g0;                                                 // inside the general probes
+#if SNK_STATS + 0 >= 3
+            const unsigned long long stat_g1 = clock64();
+            if (stat_be && lane == 0u) atomicAdd(&snk_stats[34], stat_g1 - stat_g0);
+#endif
 #endif
             // (a finished lane goes back to the hand-out -- unless that would hold it anyway: sets with exceptions hand the next
             // batch out only when the wave's whole batch has ended, and a pass through the top of the loop for nothing re-runs
@@ -2364,6 +2446,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         }
 #ifdef SNK_STATS
         P.rounds_cyc += clock64() - stat_i0;
+        if (stat_be) { P.be_cyc += clock64() - stat_o0; P.be_n++; P.be_rounds += P.rounds - stat_r0; }      // (top + rounds; finish and prologue are per entry)
 #endif
         if (refill) continue;
         if (!__any(have)) continue;              // the last working lane has just finished: hand out / leave

@@ -12,7 +12,7 @@ for c in $CODECS; do
   sfx=$([ $c = lz4 ] && echo "" || echo "_$c")
   python3 bench.py --codec $c > "$OUT/bench$sfx.json" 2> "$OUT/bench$sfx.err" || exit 1
   echo "bench $c: $(cut -c1-160 $OUT/bench$sfx.json)"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$c" -- python3 bench.py --codec $c --steps 4 --warmup 1 --no-cpu-baseline --no-matrix --no-cli-wall > "$OUT/kt_$c.log" 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$c" -- python3 bench.py --codec $c --steps 4 --warmup 1 --no-cpu-baseline --no-matrix --no-cli-wall --no-secondary > "$OUT/kt_$c.log" 2>&1 || exit 1
   f=$(find "$OUT/kt_$c" -name '*kernel_stats.csv' | head -1)
   python3 - "$f" "$OUT/kernel_stats_bench${sfx}_1024x1Mbp_84rows.csv" <<'PY'
 import csv, sys
