@@ -44,7 +44,8 @@ out = {"genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
        # passes between two loop entries that serve a block end (a lane past its block's last probe position): top + rounds
        "block_end_passes": {"per_pair": a[63] * 21.0 / pairs, "cycles_top_and_rounds": a[62] / max(1, a[63]), "rounds": a[55] / max(1, a[63]),
                             "other_passes_cycles_top_and_rounds": (a[25] + a[29] - a[62]) / max(1, entries - a[63])},
-       "per_exit": {"finish": a[24] / entries, "general_rounds_and_reseat": a[25] / entries, "rounds": a[26] / entries, "prologue": a[27] / entries},
+       "per_exit": {"finish": a[24] / entries, "general_rounds_and_reseat": a[25] / entries, "rounds": a[26] / entries, "prologue": a[27] / entries, "top_of_the_wave_loop": a[29] / entries,
+                    "elsewhere": (a[7] - a[13] - a[24] - a[25] - a[27] - a[29]) / entries},
        "service_requests_per_pair": {k: c[i] / pairs for i, k in [(16, "literal run >= 15"), (17, "back-extension 4"), (18, "output budget"),
                                                                   (19, "12 equal bases"), (20, "block end"), (21, "other limit"), (22, "seam straddle")]}}
 out["collected_at_commit"] = sys.argv[3] if len(sys.argv) > 3 else "?"
