@@ -337,7 +337,7 @@ def test_bench_reads_the_committed_profile_summaries():
     for codec in ("lz4", "gzip", "zlib"):
         traffic, src = bench.pmc_traffic(84, 1024, 1000000, codec)
         assert traffic and traffic > 0 and src.startswith("profiles/r0") and "pmc_traffic" in src, (codec, traffic, src)
-    assert bench.pmc_traffic(84, 1024, 1000000, "lz4")[1].startswith("profiles/r03_pmc_traffic.json @ ")
+    assert bench.pmc_traffic(84, 1024, 1000000, "lz4")[1].startswith("profiles/r04_pmc_traffic.json @ ")
     assert "?" not in bench.pmc_traffic(84, 1024, 1000000, "lz4")[1]                  # names its commit
     assert bench.pmc_traffic(84, 1000, 1000000)[0] is None           # another launch shape: no figure
     # (round 4) the secondary data sets have counters of their own; a set measured on another launch shape has no figure
