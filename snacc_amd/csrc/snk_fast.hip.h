@@ -2420,7 +2420,25 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
 #endif
             bool stat_done = false;
             const bool edge = !ok && !oel && L.cur + L.step > L.mfl1;      // this lane closes a block / opens the next one in this round
-            if (!ok && !oel && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; }   // frame complete
+            bool served = !ok && !oel;
+            if (served && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; served = false; }   // frame complete
+            if (EXC) {
+                // A lane served at a site goes on with general probes HERE for as long as its cursor window holds a byte of another
+                // class than the rest of it (the 16 cursors around the edge of a soft-masked stretch, an IUPAC code, a run of N):
+                // a round of this loop costs the wave ~7 k cycles of which the probe is 2.8 k -- the site scan, the eligibility
+                // tests, the other-case scan, the ballots are the rest -- and a stretch's two edges were ~27 rounds.  A general
+                // probe is right at any position; the round's logic looks at the lane again when the window is of one class
+                // (or after 24 probes).
+                for (uint32_t n = 0; n < 24u; ++n) {
+                    bool more = false;
+                    if (served && have && L.cur + L.step <= L.mfl1 && (L.cur >= L.s.lx + 4u || (L.cur >= 4u && L.cur + 12u <= L.s.lx))) {
+                        const uint32_t cw = snk_fetch32m(L.s, L.cur);
+                        more = cw != 0u && cw != 0x55555555u;
+                    }
+                    if (!__any(more)) break;
+                    if (more && snk_fast_iter<EXC, FAR>(L, T, tbl, bm, gt, slot, out, status)) { have = false; stat_done = true; served = false; }
+                }
+            }
             // (a block edge the block step has not seated the reservoir for -- the first block inside y, the seam --: seated here
             // instead of in a round of its own)
             if (!EXC && !FAR && edge && have && L.in_block && L.cur + L.step <= L.mfl1 && !snk_fast_eligible<EXC>(L)) {      // (else seated by the block step)
