@@ -42,7 +42,7 @@ out = {"genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
        "cycles_per_exit_outside_loop": (a[7] - a[13]) / entries,
        "share_outside_loop": (a[7] - a[13]) / a[7],
        # passes between two loop entries that serve a block end (a lane past its block's last probe position): top + rounds
-       "block_end_passes": {"per_pair": a[63] * 21.0 / pairs, "cycles_top_and_rounds": a[62] / max(1, a[63]), "rounds": a[55] / max(1, a[63]),
+       "block_end_passes": {"per_wave_job_of_21_pairs": a[63] * 21.0 / pairs, "cycles_top_and_rounds": a[62] / max(1, a[63]), "rounds": a[55] / max(1, a[63]),
                             "other_passes_cycles_top_and_rounds": (a[25] + a[29] - a[62]) / max(1, entries - a[63])},
        "per_exit": {"finish": a[24] / entries, "general_rounds_and_reseat": a[25] / entries, "rounds": a[26] / entries, "prologue": a[27] / entries, "top_of_the_wave_loop": a[29] / entries,
                     "elsewhere": (a[7] - a[13] - a[24] - a[25] - a[27] - a[29]) / entries},
