@@ -744,10 +744,32 @@ __device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur
 // Finish the probe at `cur` whose table operations are already done and whose candidate is `cand`
 // (valid or not): general window fetches (any source, seam included), liblz4's exact match
 // accounting.  This is where the steady loop hands over whenever a lane needs service.
+// (a vote of the lanes that are active HERE; the emulation's lane is alone wherever it stands -- its pair exists only inside
+// the two-lane loop)
+#ifdef SNK_HOST_EMU
+#define SNK_ALL_ACTIVE(p) (p)
+#else
+#define SNK_ALL_ACTIVE(p) __all(p)
+#endif
 __device__ __forceinline__ void snk_fast_finish(SnkFastLane &L, uint32_t cur, uint32_t cand, bool valid)
 {
-    const uint32_t wc = snk_fetch32(L.s, cur);
-    const uint32_t wd = snk_fetch32(L.s, valid ? cand : cur);
+    // (both windows inside one sequence for every lane -- the rule away from the seam --: two loads in flight together; the
+    // compiler makes a branch with its own wait of each snk_fetch32, one global round trip after the other at every exit)
+    uint32_t wc, wd;
+    {
+        const uint32_t pd = valid ? cand : cur, lx = L.s.lx;
+        const bool cy = cur >= lx + 4u, dy = pd >= lx + 4u;
+        if (SNK_ALL_ACTIVE((cy || cur + 12u <= lx) && (dy || pd + 12u <= lx))) {
+            const int32_t qc = (int32_t)cur - 4 - (cy ? (int32_t)lx : 0), qd = (int32_t)pd - 4 - (dy ? (int32_t)lx : 0);
+            const uint64_t vc = snk_ld8g(L.s.arena + (size_t)(uint32_t)((int32_t)(cy ? L.s.yoff : L.s.xoff) + (qc >> 2)));
+            const uint64_t vd = snk_ld8g(L.s.arena + (size_t)(uint32_t)((int32_t)(dy ? L.s.yoff : L.s.xoff) + (qd >> 2)));
+            wc = __builtin_amdgcn_alignbit((uint32_t)(vc >> 32), (uint32_t)vc, (uint32_t)(qc & 3) * 2u);
+            wd = __builtin_amdgcn_alignbit((uint32_t)(vd >> 32), (uint32_t)vd, (uint32_t)(qd & 3) * 2u);
+        } else {
+            wc = snk_fetch32(L.s, cur);
+            wd = snk_fetch32(L.s, pd);
+        }
+    }
     const uint32_t x = wc ^ wd;
     const uint32_t f = (uint32_t)__builtin_ctz((x >> 8) | (1u << 24)) >> 1;          // equal bases from cur, 0..12
     SNK_TRACE_REC(6u, cur, cand, (f << 24) | (valid ? 0x400000u : 0u), cur);
