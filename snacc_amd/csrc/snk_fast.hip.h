@@ -698,6 +698,9 @@ __device__ __forceinline__ bool snk_fast_block_step(SnkFastLane &L, const SnkTab
 
 // Rare path of a match: long back-extension, long match, length-extension bytes, output
 // budget, end of block -- liblz4's exact accounting.
+#ifndef SNK_EXT_BASES
+#define SNK_EXT_BASES 128u         // bases per step of a long match's extension (a multiple of 32)
+#endif
 // xb: the difference of the two windows' first four bases (cur-4 .. cur-1 against cand-4 .. cand-1, bits 0..7): the back-extension
 // starts on them -- no load for the usual 0..3 bases; every exit of the loop has a lane or two in here, and the loop's first
 // compare used to cost the wave a global round trip.
@@ -715,13 +718,42 @@ __device__ __forceinline__ void snk_fast_match_slow(SnkFastLane &L, uint32_t cur
             while (ip > anchor0 && cand > 0u && snk_base_at(s, ip - 1u) == snk_base_at(s, cand - 1u)) { ip--; cand--; lit--; }
     }
     uint32_t e2 = cur + f;
-    if (f == 12u) {                                          // keep counting, 16 bases at a time
+    if (f == 12u) {
+        // keep counting: SNK_EXT_BASES at a time where both runs lie inside one sequence, all loads of a step in flight together
+        // (a tandem repeat is a match of hundreds of bases: at 16 bases per pair of dependent loads the Markov set spent 7.4 k
+        // cycles per loop exit in here, profiles/r04_cycle_account_markov.json); 16 at a time across the seam.  (Reads beyond a
+        // sequence stay inside the arena's slack; the count is clamped below.  Issuing the next step's loads ahead of this
+        // step's compare was measured too: slower, on this set and on the LCG set -- the code grows in front of the loop.)
         uint32_t bpos = cand + (cur - ip) + 12u;
+        const uint32_t lx = s.lx;
         while (e2 < L.mlimit) {
-            const uint32_t d = snk_fetch32(s, e2 + 4u) ^ snk_fetch32(s, bpos + 4u);
-            const uint32_t cnt = d ? ((uint32_t)__builtin_ctz(d) >> 1) : 16u;
+            const bool ey = e2 >= lx, by = bpos >= lx;
+            uint32_t cnt, full;
+            if ((ey || e2 + SNK_EXT_BASES <= lx) && (by || bpos + SNK_EXT_BASES <= lx)) {
+                const uint32_t qe = e2 - (ey ? lx : 0u), qb = bpos - (by ? lx : 0u);
+                snk_g8 *pe = s.arena + (size_t)((ey ? s.yoff : s.xoff) + (qe >> 2));
+                snk_g8 *pb = s.arena + (size_t)((by ? s.yoff : s.xoff) + (qb >> 2));
+                constexpr uint32_t NW = SNK_EXT_BASES / 32u;
+                uint64_t ew[NW + 1u], bw[NW + 1u];
+#pragma unroll
+                for (uint32_t k = 0; k <= NW; ++k) { ew[k] = snk_ld8g(pe + 8u * k); bw[k] = snk_ld8g(pb + 8u * k); }
+                const uint32_t she = 2u * (qe & 3u), shb = 2u * (qb & 3u);
+                cnt = SNK_EXT_BASES;
+#pragma unroll
+                for (uint32_t k = NW; k-- > 0u; ) {                     // (from the far end: the nearest difference wins)
+                    const uint64_t ea = she ? (ew[k] >> she) | (ew[k + 1u] << (64u - she)) : ew[k];
+                    const uint64_t ba = shb ? (bw[k] >> shb) | (bw[k + 1u] << (64u - shb)) : bw[k];
+                    const uint64_t d = ea ^ ba;
+                    cnt = d ? 32u * k + ((uint32_t)__builtin_ctzll(d) >> 1) : cnt;
+                }
+                full = SNK_EXT_BASES;
+            } else {
+                const uint32_t d = snk_fetch32(s, e2 + 4u) ^ snk_fetch32(s, bpos + 4u);
+                cnt = d ? ((uint32_t)__builtin_ctz(d) >> 1) : 16u;
+                full = 16u;
+            }
             e2 += cnt; bpos += cnt;
-            if (cnt < 16u) break;
+            if (cnt < full) break;
         }
     }
     if (e2 > L.mlimit) e2 = L.mlimit;

@@ -304,6 +304,29 @@ def test_long_matches_and_low_complexity(hip, oracle_mod):
     assert _check_all(hip, oracle_mod, seqs) == 6
 
 
+def test_long_matches_that_run_up_to_and_across_the_seam(hip, oracle_mod):
+    """The extension of a match beyond 12 bases reads 128 bases a step where both runs lie inside one sequence, with the next
+    step's loads issued ahead, and 16 a step across the seam (round 4).  y starts with a copy of x's last 300 .. 1300 bases -- the
+    candidate's run walks through the end of x into y's first bases -- for every residue of len(x) mod 4, with the copy broken
+    after 13 .. 700 bases, next to x's whose tail is a tandem repeat (runs of both sides inside one sequence, every phase)."""
+    o = oracle_mod
+    rng = np.random.default_rng(4128)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for k in range(8):
+        lx = 20000 + k                                           # every residue mod 4, twice
+        x = o.lcg_genome(900 + k, lx).copy()
+        if k >= 4:
+            unit = int(rng.integers(3, 90)); x[-2000:] = np.tile(x[-2000:-2000 + unit], 2000 // unit + 1)[:2000]
+        tail = int(rng.integers(300, 1300))
+        y = np.concatenate([x[-tail:], o.lcg_genome(950 + k, 5000 + 3 * k)])
+        cut = int(rng.integers(13, 700))
+        y[cut] = acgt[(np.flatnonzero(acgt == y[cut])[0] + 1) % 4]          # the copy ends here
+        seqs += [x, y]
+    assert _check_all(hip, oracle_mod, seqs) == len(seqs)
+    assert _check_all(hip, oracle_mod, seqs, fast_asm=0, fast_spec=0) == len(seqs)
+
+
 def _tandem(rng, n, unit_len, rate):
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     a = np.tile(rng.choice(acgt, unit_len), n // unit_len + 1)[:n].copy()

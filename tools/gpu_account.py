@@ -1,7 +1,7 @@
 """Dev aid (GPU box): cycle account of the 2-bit kernel's waves from the stats build (`make -C snacc_amd/csrc stats`).
 Runs a row tile once with the hand-scheduled loop (cycles) and once with its C++ statement (trips and service reasons: the two
 loops make the same trips), and prints cycles per trip, the cost of leaving and re-entering the loop, and why lanes ask for service.
-Usage: SNACC_HIP_LIB=$PWD/snacc_amd/libsnacc_hip_stats.so python tools/gpu_account.py [N L]   (default 256 x 1 Mbp, rows = chains)"""
+Usage: [DATA=lcg|markov|related] SNACC_HIP_LIB=$PWD/snacc_amd/libsnacc_hip_stats.so python tools/gpu_account.py [N L COMMIT]   (default 256 x 1 Mbp, rows = chains)"""
 import ctypes
 import json
 import sys
@@ -12,7 +12,15 @@ from snacc_amd.hip_backend import HipContext
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
-seqs = [oracle.lcg_genome(1 + i, L) for i in range(N)]
+import os
+DATA = os.environ.get("DATA", "lcg")                     # lcg | markov | related: bench.py's data sets
+if DATA == "lcg":
+    seqs = [oracle.lcg_genome(1 + i, L) for i in range(N)]
+else:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    seqs = bench.markov_genomes_torch(N, L, "cuda:0") if DATA == "markov" else bench.lcg_related_torch(N, L, "cuda:0")
 lib = hip_backend.load()
 if not hasattr(lib, "snk_debug_stats"):
     sys.exit("not the stats build: set SNACC_HIP_LIB to libsnacc_hip_stats.so")
@@ -34,7 +42,7 @@ rows, ms, a = run(1)
 _, _, c = run(0)
 pairs = rows * N
 trips, entries = c[15], a[14]
-out = {"genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
+out = {"data": DATA, "genomes": N, "length": L, "rows": rows, "pairs": pairs, "kernel_ms": ms,
        "wave_trips": trips, "loop_entries": entries, "trips_per_entry": trips / entries,
        "cycles_per_trip_in_loop": a[13] / trips,
        # two lanes per chain (the default): a chain-trip is role 0's probe plus role 1's when it counted
