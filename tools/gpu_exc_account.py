@@ -11,6 +11,7 @@ from snacc_amd.hip_backend import HipContext
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 PCT = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+OPTS = {k.split('=')[0]: int(k.split('=')[1]) for k in sys.argv[4:] if '=' in k}       # context options, e.g. fast_spec=0
 rng = np.random.default_rng(11)
 seqs = []
 nst = max(1, L * PCT // 100 // 500)
@@ -24,7 +25,7 @@ if not hasattr(lib, "snk_debug_stats"):
     sys.exit("not the stats build")
 def run(asm):
     st = (ctypes.c_ulonglong * 64)()
-    with HipContext(0, fast_asm=asm) as ctx:
+    with HipContext(0, fast_asm=asm, **OPTS) as ctx:
         ctx.upload(seqs)
         lib.snk_debug_stats(st)
         rows = ctx.fast_chains()
