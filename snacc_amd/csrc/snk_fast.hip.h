@@ -1249,6 +1249,9 @@ __device__ __forceinline__ void snk_fast_exc_handover(SnkFastLane &L, const uint
 // A lane may run the steady loop when its next probe is an ordinary one: inside an open block
 // that has not bailed out, search step 1, literal run and output budget far from their rare
 // ranges, cursor served by the reservoir's source.
+#ifndef SNK_EXC_WAITMAX
+#define SNK_EXC_WAITMAX 64u      // (exceptions) ... or have waited this many rounds of the wave loop
+#endif
 #ifndef SNK_EXC_GATHER
 #define SNK_EXC_GATHER    16384u   // (exceptions) lanes waiting at a site are served once no running lane is fewer bases behind them
 #endif
@@ -2381,7 +2384,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
                 const bool runner = have && !parked && waiting == 0u && L.cur >= L.s.lx && L.s.yoff == wy;
                 const uint32_t ry = L.cur - L.s.lx;
                 const bool soon = runner && ry < wfront && wfront - ry < SNK_EXC_GATHER;
-                if (in_x || !__any(soon) || __any(waiting > 64u)) { flushing = true; if (lane == 0u) SNK_COUNT(3); }
+                if (in_x || !__any(soon) || __any(waiting > SNK_EXC_WAITMAX)) { flushing = true; if (lane == 0u) SNK_COUNT(3); }
             }
             if (flushing) waiting = 0u;
             else if (waiting) waiting++;
