@@ -69,6 +69,27 @@ def test_emu_repeats_long_matches_and_runs():
     check(rep)
 
 
+@pytest.mark.parametrize("k0", (0, 2))
+def test_emu_long_matches_up_to_and_across_the_seam(k0):
+    """(round 4) y starts with a copy of x's last few hundred bases, broken after 13 .. 700 of them: the candidate's run of a long
+    match walks through the end of x into y -- 128 bases a step inside one sequence, 16 across the seam -- for two residues of
+    len(x) mod 4 per call; the second x ends in a tandem repeat."""
+    rng = np.random.default_rng(4128 + k0)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for k in (k0, k0 + 1):
+        lx = 66000 + k
+        x = oracle.lcg_genome(900 + k, lx).copy()
+        if k & 1:
+            unit = int(rng.integers(3, 90)); x[-2000:] = np.tile(x[-2000:-2000 + unit], 2000 // unit + 1)[:2000]
+        tail = int(rng.integers(300, 1300))
+        y = np.concatenate([x[-tail:], oracle.lcg_genome(950 + k, 3000 + 3 * k)])
+        cut = int(rng.integers(13, 700))
+        y[cut] = acgt[(np.flatnonzero(acgt == y[cut])[0] + 1) % 4]
+        seqs += [x, y]
+    check(seqs)
+
+
 def test_emu_relatives():
     a = oracle.lcg_genome(41, 180000)
     check([a, oracle.lcg_mutant(a, 3), oracle.lcg_mutant(a, 4)[1000:], oracle.lcg_genome(42, 90000)])
