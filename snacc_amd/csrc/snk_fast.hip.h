@@ -1726,8 +1726,8 @@ __device__ __forceinline__ uint32_t snk_pair_swap(uint32_t v)          // the pa
 #define SNK_PAIR_TAKE(v) do { const uint32_t sw_ = snk_pair_swap((uint32_t)(v)); if (R1) (v) = sw_; } while (0)
 
 template <bool ASM, bool EXC>
-__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, snk_g8 *const arena, snk_g8 *const marena,
-                                                     uint16_t *tbl_, uint32_t *bm_, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
+__device__ __forceinline__ void snk_fast_steady_spec_once(SnkFastLane &L, const bool R1, snk_g8 *const arena, snk_g8 *const marena,
+                                                          uint16_t *tbl_, uint32_t *bm_, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
 {
 #ifdef SNK_STATS
     const unsigned long long stat_te = clock64();
@@ -1936,6 +1936,45 @@ __device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool 
     L.w.rb = 0x80000000u;
     if (EXC) snk_fast_exc_handover(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
     else     snk_fast_finish(L, vb + c, (uint32_t)(T0 + (int32_t)t), valid);
+}
+
+// A chain that leaves the loop inside a block seats its reservoir again from the source it was reading.
+__device__ __forceinline__ void snk_fast_reseat_same(SnkFastLane &L)
+{
+    const uint32_t cur = L.cur, lx = L.s.lx;
+    if (cur + L.step > L.mfl1) return;
+    if (cur >= lx + 4u && L.w.org == lx && L.w.soff == L.s.yoff && L.w.lim == 0xFFFFFFFFu)
+        snk_win_init(L.w, L.s.arena, L.s.yoff, lx, 0xFFFFFFFFu, cur);
+    else if (cur >= 4u && cur + 12u <= lx && L.w.org == 0u && L.w.soff == L.s.xoff && L.w.lim == lx - 12u)
+        snk_win_init(L.w, L.s.arena, L.s.xoff, 0u, lx - 12u, cur);
+}
+
+// The two-lane loop with a quick turn-around (round 4, pure ACGT): when every chain of the run can go straight back into the loop
+// after its hand-over -- inside its block, the reservoir's source unchanged, nothing for the general path to do: a match that ran
+// past the 12-base window, a long back-extension, a reservoir at its source's limit... -- the wave does, from here, instead of
+// through the head of the wave loop, whose compiled generality (job hand-out, the rounds and their votes, the block step: ~1 300
+// vector instructions per pass at one wave per SIMD) was 4 k of such an exit's 6 k cycles.  A block end, the seam, a finished
+// frame, a lane that needs a general probe: back to the head as before.
+// Block ends too (half of the exits on genome data): a chain whose block is followed by another full-sized step of the same frame
+// -- no snapshot to write, not the frame's end -- takes the block step right here; it seats the new block's reservoir itself.
+template <bool ASM, bool EXC>
+__device__ __forceinline__ void snk_fast_steady_spec(SnkFastLane &L, const bool R1, const SnkTables &T, const uint16_t *slot, uint32_t *out, uint32_t *status,
+                                                     uint16_t *tbl_, uint32_t *bm_, uint32_t lds_off, uint32_t round_bases SNK_PROF_ARG)
+{
+    snk_g8 *const arena = (snk_g8 *)T.packed_arena, *const marena = (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena);
+    for (;;) {
+        snk_fast_steady_spec_once<ASM, EXC>(L, R1, arena, marena, tbl_, bm_, lds_off, round_bases SNK_PROF_PASS);
+        if (EXC) return;
+        bool again = true;
+        if (!R1) {
+            if (L.cur + L.step > L.mfl1 && L.in_block && L.iend < L.n && L.n - L.iend >= 13u && L.blocks_left != 0u &&
+                !(L.snap != 0 && L.iend == L.spos))
+                (void)snk_fast_block_step<false, false>(L, T, tbl_, bm_, nullptr, slot, out, status);      // (returns false: a block follows)
+            if (!snk_fast_eligible<false>(L)) snk_fast_reseat_same(L);
+            again = snk_fast_eligible<false>(L);
+        }
+        if (!__all(again)) return;                 // (the lanes of this run; role 1 goes where its chain goes)
+    }
 }
 
 #ifndef SNK_HOST_EMU
@@ -2551,8 +2590,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
         if (SPEC) {     // the emulated lane is role 0 of its pair; its partner lives for the duration of the loop (snk_host_emu.h)
             if (have && !parked && waiting == 0u && round != 0u)
                 snk_emu_pair_run([&](bool r1, SnkFastLane &Lr) {
-                    snk_fast_steady_spec<false, EXC>(Lr, r1, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena),
-                                                     tbl, bm, mine_off, round SNK_PROF_PASS);
+                    snk_fast_steady_spec<false, EXC>(Lr, r1, T, slot, out, status, tbl, bm, mine_off, round SNK_PROF_PASS);
                 }, L);
         } else
 #else
@@ -2565,8 +2603,7 @@ __device__ __forceinline__ void snk_fast_wave(const SnkTables &T, const SnkFastG
             const bool go = have && !parked && waiting == 0u && round != 0u;
             const bool pgo = snk_pair_swap(go ? 1u : 0u) != 0u;                 // (every lane of the wave is active here)
             if (go || ((lane & 1u) && pgo))
-                snk_fast_steady_spec<ASM, EXC>(L, (lane & 1u) != 0u, (snk_g8 *)T.packed_arena, (snk_g8 *)(EXC ? T.mask_arena : T.packed_arena),
-                                               tbl, bm, mine_off, round SNK_PROF_PASS);
+                snk_fast_steady_spec<ASM, EXC>(L, (lane & 1u) != 0u, T, slot, out, status, tbl, bm, mine_off, round SNK_PROF_PASS);
         } else
 #endif
         if (have && !parked && waiting == 0u && round != 0u)
