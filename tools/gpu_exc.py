@@ -6,9 +6,12 @@ sys.path.insert(0, '.')
 import oracle
 from snacc_amd.hip_backend import HipContext
 N, L, R0 = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-rng = np.random.default_rng(11)
 base = [oracle.lcg_genome(1 + i, L) for i in range(N)]
 def variant(kind):
+    # (every kind draws its places from its own generator: the same data whatever else is on the command line -- until round 4 one
+    # generator served all kinds in turn, and a set's rate moved by 10 % with the ORDER of the kinds)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 11)
     out = []
     for a in base:
         a = a.copy()
