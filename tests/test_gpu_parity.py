@@ -97,6 +97,18 @@ def test_ragged_lengths_around_block_edges(hip, oracle_mod):
     _check_all(hip, oracle_mod, seqs)
 
 
+def test_last_blocks_of_every_short_length_after_the_loops_own_turn_around(hip, oracle_mod):
+    """(round 4) The two-lane loop takes a block step on its own when another full step of the same frame follows -- at least 13
+    bytes, not the frame's end, no snapshot to write -- and goes back to the head of the wave loop otherwise.  Pairs whose
+    stream is 3 blocks plus 0 .. 14 bytes (and a few more) stand on both sides of every one of those conditions; singles of the same
+    lengths are the snapshot side (phase A writes its snapshot at the last block edge)."""
+    x = oracle_mod.lcg_genome(77, 70000)
+    tails = [0, 1, 4, 5, 11, 12, 13, 14, 15, 100, 65535]
+    seqs = [x] + [oracle_mod.lcg_genome(78 + d, 3 * 65536 - 70000 + d) for d in tails]
+    seqs += [oracle_mod.lcg_genome(60, 2 * 65536 + d) for d in (0, 12, 13)]
+    assert _check_all(hip, oracle_mod, seqs) == len(seqs)
+
+
 def test_mixed_alphabets_raw_blocks_and_n_runs(hip, oracle_mod):
     rng = np.random.default_rng(7)
     o = oracle_mod

@@ -55,6 +55,14 @@ def test_emu_ragged_block_edges():
     check([oracle.lcg_genome(11 + k, n) for k, n in enumerate(lens)])
 
 
+def test_emu_last_blocks_of_every_short_length():
+    """(round 4) the loop's own turn-around takes a block step when another full step of the same frame follows: streams of 2 blocks
+    plus 0 .. 14 bytes stand on both sides of each of its conditions (lane pair: the wrapper's vote is a pair exchange)."""
+    x = oracle.lcg_genome(77, 70000)
+    tails = [0, 1, 5, 12, 13, 14]
+    check([x] + [oracle.lcg_genome(78 + d, 2 * 65536 - 70000 + d) for d in tails])
+
+
 def test_emu_lengths_mod_4_and_seams():
     # every residue of len(x) mod 4 (the phase of y inside the packed words) and seams next to block edges
     lens = [100001, 100002, 100003, 100004, 65530, 65533, 131069, 131075, 5, 6, 7]
