@@ -107,6 +107,10 @@ void snk_ctx_destroy(snk_ctx *ctx);
  *                   lane probes 5 bases ahead; exact); 0 = one lane per chain; 3 / 36 = three lanes per chain as a C++
  *                   statement (a third lane 10 / 6 bases ahead; 20 chains per wave; pure-ACGT sets; exact) -- built and
  *                   measured negative in round 4 (profiles/r04_third_lane.json), kept for reproduction
+ *   "split_clean"   (round 4) in a resident set where only SOME 2-bit sequences carry exceptions, the pairs of two sequences without
+ *                   any are listed first and run on the pure-ACGT kernel (an exception kernel's loop exits cost four times as much):
+ *                   0 never, 1 (default) when those pairs alone fill the card 16 times -- a second launch leaves the card part-empty
+ *                   once more --, 2 always (tests).  Sizes are the same either way.
  *   "defer_singles" 1 = snk_upload / snk_upload_fasta leave phase A (single sizes + prefix snapshots) to the calls that
  *                   need it: snk_singles / snk_singles_rows for the rows asked for, the snk_pairs* calls for the rows
  *                   (prefixes) they compute.  A rank of a row-sharded run thus computes its own rows only, and a

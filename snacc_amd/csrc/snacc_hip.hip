@@ -100,6 +100,8 @@ struct snk_ctx_impl {
     uint32_t *d_lut_hash = nullptr, *d_hashset = nullptr;      // d_hashset: 128 words (hash5) + 256 words (hash4)
     uint32_t *d_single = nullptr, *d_status = nullptr;
     bool singles_done = false;       // snk_upload has completed: sequences resident (phase A may still be owed, see single_have)
+    size_t n_fast_clean = 0;         // (build_jobs) how many of the list's 2-bit jobs pair two sequences WITHOUT exceptions: they come first
+    int split_clean = 1;             // option: such pairs of a set with exceptions run on the pure kernel (0 never, 1 when they fill the card 16 times, 2 always)
     bool defer_singles = false;      // option: snk_upload leaves phase A (single sizes + prefix snapshots) to the calls that need it,
                                      // row by row -- a rank of a sharded run computes its own rows only, a gzip / zlib run none
     std::vector<uint8_t> single_have;   // per sequence: phase A done
@@ -369,9 +371,16 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                 uint32_t *d_out, bool singles = false, const SnkTileDesc *tile = nullptr)
 {
     SnkTables T = make_tables(c);
-    if (n_fast) {
+    // (round 4) A set in which only SOME sequences carry exceptions: the pairs of two clean sequences -- the first n_clean 2-bit jobs of
+    // the list, build_jobs puts them there -- run on the pure kernel (an exception kernel's ordinary loop exit costs four times the
+    // pure kernel's); same geometry, same tables, one launch after the other on the stream.
+    const size_t n_clean = (!singles && c->any_exc && !(tile && tile->rows > 0)) ? std::min(c->n_fast_clean, n_fast) : 0;      // (build_jobs decides)
+    for (int grp = 0; grp < 2; ++grp) {
+        const size_t nf_g = grp == 0 ? (n_clean ? n_clean : n_fast) : (n_clean ? n_fast - n_clean : 0);
+        if (!nf_g) continue;
+        const SnkJob *const jl_g = grp == 0 ? d_jobs : d_jobs + n_clean;
         uint32_t waves = (uint32_t)c->fast_waves;
-        const bool exc = c->any_exc;      // some resident 2-bit sequence has exceptions: the instantiations that know about them
+        const bool exc = c->any_exc && !(n_clean && grp == 0);      // some resident 2-bit sequence has exceptions: the instantiations that know about them
         uint32_t lanes = 0, short_last = 0;
         if (fast_geometry(c, &lanes, &short_last) != SNK_OK) return SNK_E_ARG;
         if (singles && c->fast_lanes == 0) {
@@ -384,10 +393,10 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
             // ceil(N / CUs) chains 48 ms.  So: one wave per workgroup while 21 chains per CU cover the jobs, more waves beyond.
             const uint64_t cus = (uint64_t)std::max(c->n_cus, 1);
             const uint32_t full = lanes;                                  // chains per wave the LDS allows at c->fast_waves
-            waves = (uint32_t)std::min<uint64_t>(waves, std::max<uint64_t>(1u, (n_fast + cus * full - 1u) / (cus * full)));
-            lanes = std::min<uint32_t>(full, (uint32_t)std::max<uint64_t>(1u, (n_fast + cus * waves - 1u) / (cus * waves)));
+            waves = (uint32_t)std::min<uint64_t>(waves, std::max<uint64_t>(1u, (nf_g + cus * full - 1u) / (cus * full)));
+            lanes = std::min<uint32_t>(full, (uint32_t)std::max<uint64_t>(1u, (nf_g + cus * waves - 1u) / (cus * waves)));
         }
-        const bool tri = (c->fast_spec == 3 || c->fast_spec == 36) && !exc && !singles && c->far_lanes == 0;     // three lanes per chain: 5 chains per 16-lane row
+        const bool tri = (c->fast_spec == 3 || c->fast_spec == 36) && !c->any_exc && !singles && c->far_lanes == 0;     // three lanes per chain: 5 chains per 16-lane row
         if (tri && lanes > 20u) lanes = 20u;
         const uint32_t chains = lanes * waves;
         const size_t lds = (c->any_other ? 2u : 1u) * (size_t)SNK_FLUT_B + (size_t)(chains - short_last) * SNK_FCHAIN_B;
@@ -395,9 +404,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         G.short_last = short_last; G.flut = (c->any_other ? 2u : 1u) * SNK_FLUT_B;
         const bool dense = tile && tile->rows > 0;
         // far chains (tables in global memory, extra waves): pair launches of pure-ACGT sets that fill the card
-        uint32_t far_waves = (!exc && !singles && c->far_lanes > 0) ? (uint32_t)c->far_waves : 0u;
-        if (far_waves && (waves + far_waves > 8u || n_fast < (size_t)c->far_min * chains * (size_t)std::max(c->n_cus, 1))) far_waves = 0u;
-        G.jobs = dense ? nullptr : d_jobs; G.n_jobs = (uint32_t)n_fast;
+        uint32_t far_waves = (!c->any_exc && !singles && c->far_lanes > 0) ? (uint32_t)c->far_waves : 0u;
+        if (far_waves && (waves + far_waves > 8u || nf_g < (size_t)c->far_min * chains * (size_t)std::max(c->n_cus, 1))) far_waves = 0u;
+        G.jobs = dense ? nullptr : jl_g; G.n_jobs = (uint32_t)nf_g;
         G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
         const bool spec = c->fast_spec != 0 && far_waves == 0u && lanes <= 32u;       // two lanes per chain
@@ -416,7 +425,7 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
                 return fail(c, SNK_E_STATE, "snk_fast_kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
         }
         // persistent launch: one workgroup per compute unit at most (the LDS admits one), waves walk the batches
-        uint32_t grid = (uint32_t)((n_fast + chains - 1) / chains);
+        uint32_t grid = (uint32_t)((nf_g + chains - 1) / chains);
         if (c->n_cus > 0 && grid > (uint32_t)c->n_cus) grid = (uint32_t)c->n_cus;
         // (far waves are slower per chain than LDS waves: only the atomic queue keeps both kinds busy)
         const bool dynamic = far_waves ? true : c->fast_dynamic < 0 ? (singles || (tile && tile->ragged)) : c->fast_dynamic != 0;
@@ -600,6 +609,11 @@ bool pair_is_fast(const snk_ctx_impl *c, int i, int j)
            (uint64_t)c->len[i] + c->len[j] > SNK_BLOCK;
 }
 
+// Two launches leave the card part-empty twice at their ends (a round of jobs too many in the worst case): measured at 1024 x 1 Mbp
+// with ten runs of N in 10 % of the genomes, the full matrix (49 rounds of the card) + 7.6 %, 336 rows (16 rounds) - 1.8 %, 84 rows
+// (4 rounds) - 18 %.  So a list is split (option split_clean = 1) only when its clean part alone fills the card 16 times.
+size_t split_threshold(const snk_ctx_impl *c) { return (size_t)16 * 84u * (size_t)std::max(c->n_cus, 1); }
+
 // Build the job list for an arbitrary set of ordered pairs (i, j) -> out index.
 // Fast jobs are ordered by suffix sequence j so that the chains of one workgroup
 // walk the same bytes (L1/L2 locality); generic jobs follow.
@@ -620,7 +634,19 @@ int build_jobs(snk_ctx_impl *c, size_t n_pairs, PairAt pair_at, size_t &n_fast, 
         else gen.push_back(jb);
     }
     n_fast = fast.size(); n_bytes = bytes.size(); n_gen = gen.size();
-    c->dense_tile = n_fast == n_pairs;
+    c->n_fast_clean = 0;
+    if (c->split_clean && c->any_exc && !fast.empty()) {
+        // pairs of two sequences without exceptions first (each part keeps its suffix-major order) -- when launch_jobs will split the
+        // list (see there); a list that stays whole keeps its order: its waves' chains share their suffixes
+        const auto clean = [&](const SnkJob &jb) { return !c->has_exc[(size_t)jb.xi] && !c->has_exc[(size_t)jb.yi]; };
+        const size_t n_cl = (size_t)std::count_if(fast.begin(), fast.end(), clean);
+        if (n_cl == fast.size()) c->n_fast_clean = n_cl;
+        else if (n_cl && (c->split_clean == 2 || n_cl >= split_threshold(c))) {
+            std::stable_partition(fast.begin(), fast.end(), clean);
+            c->n_fast_clean = n_cl;
+        }
+    }
+    c->dense_tile = n_fast == n_pairs && c->n_fast_clean == 0;
     c->h_jobs.swap(fast);
     c->h_jobs.insert(c->h_jobs.end(), bytes.begin(), bytes.end());
     c->h_jobs.insert(c->h_jobs.end(), gen.begin(), gen.end());
@@ -849,6 +875,9 @@ int snk_set_option(snk_ctx *c, const char *key, long value)
         c->fast_spec = (int)value;
     } else if (k == "defer_singles") {
         c->defer_singles = value != 0;
+    } else if (k == "split_clean") {
+        if (value < 0 || value > 2) return fail(c, SNK_E_ARG, "split_clean must be 0, 1 or 2");
+        c->split_clean = (int)value;
     } else if (k == "fast_asm") {
         c->fast_asm = value != 0;
     } else if (k == "exc_limit") {
@@ -1348,8 +1377,18 @@ int snk_pairs_device(snk_ctx *c, int r0, int r1, void *d_sizes, void *hip_stream
     size_t nf = 0, nb = 0, ng = 0;
     int rc = ensure_singles(c, r0, r1);        // the prefix snapshots of these rows (a no-op unless phase A was deferred)
     if (rc) return rc;
-    if (!c->force_generic && c->n_packed == c->n && (uint64_t)c->min_len * 2u > SNK_BLOCK && (uint64_t)c->max_len * 2u < 0x7E000000ull) {
-        nf = np; c->dense_tile = true;             // every pair fits the 2-bit kernel: no job list at all
+    // (a set in which some sequences carry exceptions and others do not goes through the list: the clean pairs run on the pure kernel)
+    bool some_clean = false;
+    if (c->split_clean && c->any_exc) {
+        size_t rows_cl = 0, cols_cl = 0;
+        for (size_t g = 0; g < (size_t)c->n; ++g) {
+            const bool cl = c->is_packed[g] && !c->has_exc[g];
+            cols_cl += cl; rows_cl += cl && (int)g >= r0 && (int)g < r1;
+        }
+        some_clean = rows_cl && (c->split_clean == 2 || rows_cl * cols_cl >= split_threshold(c));
+    }
+    if (!c->force_generic && !some_clean && c->n_packed == c->n && (uint64_t)c->min_len * 2u > SNK_BLOCK && (uint64_t)c->max_len * 2u < 0x7E000000ull) {
+        nf = np; c->dense_tile = true; c->n_fast_clean = 0;             // every pair fits the 2-bit kernel: no job list at all
     } else {
         // order: suffix j outer, prefix i inner => the chains of a wave share seq_j
         rc = build_jobs(c, np, [&](size_t t, int &i, int &j, uint32_t &o) {

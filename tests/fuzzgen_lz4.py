@@ -20,7 +20,8 @@ CONFIGS = ({}, {"fast_asm": 0}, {"force_generic": 1}, {"bytes_compact": 0}, {"fo
            {"exc_limit": 16384},                                  # dense exceptions stay on the 2-bit kernel
            {"fast_spec": 0}, {"fast_spec": 0, "fast_asm": 0},     # one lane per chain (the default has two)
            {"fast_spec": 3}, {"fast_spec": 36, "fast_lanes": 6},  # three lanes per chain (round 4; sets without exceptions, else the default)
-           {"defer_singles": 1})                                  # phase A on demand
+           {"defer_singles": 1},                                  # phase A on demand
+           {"split_clean": 2}, {"split_clean": 2, "fast_asm": 0}) # (round 4) pairs of two clean sequences of a set with exceptions on the pure kernel
 
 
 def gen(rng, n, kind):

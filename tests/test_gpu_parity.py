@@ -445,6 +445,40 @@ def test_sequences_with_a_few_exceptions_stay_on_the_2bit_kernel(hip, oracle_mod
         assert np.array_equal(ctx.pairs(), exp_p[:7, :7])
 
 
+def test_clean_pairs_of_a_set_with_exceptions_run_on_the_pure_kernel(hip, oracle_mod):
+    """(round 4) In a set where only some sequences carry exceptions the pairs of two clean sequences are the first 2-bit jobs of
+    the launch's list and run on the pure kernel (option split_clean: 1 = when they fill the card 16 times, 2 = always, 0 = never);
+    the others on the exception kernels.  Same
+    matrix either way and as the oracle's -- with N runs / IUPAC codes only (84 chains) and with a soft-masked sequence in the set
+    (83 chains, the pure kernel on that geometry), row tiles and a pair list included."""
+    o = oracle_mod
+    rng = np.random.default_rng(77)
+    for with_soft in (False, True):
+        seqs = [o.lcg_genome(300 + i, 140000 + 3001 * i) for i in range(9)]
+        for i in (1, 4, 6):
+            a = seqs[i].copy()
+            for p0 in rng.integers(1000, a.size - 1000, 5):
+                a[p0:p0 + int(rng.integers(1, 120))] = ord("N")
+            a[rng.integers(0, a.size, 6)] = rng.choice(np.frombuffer(b"RYKMSW", dtype=np.uint8), 6)
+            seqs[i] = a
+        if with_soft:
+            a = seqs[7].copy(); a[50000:50700] |= 0x20; seqs[7] = a
+        exp = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+        got = {}
+        for split in (2, 0):
+            with hip.HipContext(0, split_clean=split) as ctx:
+                ctx.upload(seqs)
+                assert ctx.num_packed == len(seqs)
+                assert ctx.fast_chains() == (83 if with_soft else 84)
+                got[split] = ctx.pairs()
+                tile = ctx.pairs(2, 6)
+                ij = np.array([(0, 2), (2, 0), (1, 4), (3, 5), (7, 8), (8, 7), (4, 4)], dtype=np.int32)
+                lst = ctx.pairs_list(ij)
+            assert np.array_equal(got[split], exp), (with_soft, split, np.argwhere(got[split] != exp)[:6].tolist())
+            assert np.array_equal(tile, exp[2:6])
+            assert np.array_equal(lst, np.array([exp[i, j] for i, j in ij], dtype=np.uint32))
+
+
 def test_fast_chains_reports_the_workgroup_geometry(hip):
     """snk_fast_chains: lanes x waves of a 2-bit kernel workgroup; fast_lanes = 0 (the default) takes as many chains as the
     160 KiB of LDS hold beside the slot LUT: 84 at 4 waves, and explicit settings are reported as given or refused."""
