@@ -375,9 +375,25 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     // the list, build_jobs puts them there -- run on the pure kernel (an exception kernel's ordinary loop exit costs four times the
     // pure kernel's); same geometry, same tables, one launch after the other on the stream.
     const size_t n_clean = (!singles && c->any_exc && !(tile && tile->rows > 0)) ? std::min(c->n_fast_clean, n_fast) : 0;      // (build_jobs decides)
+    // (round 4) A dense tile of a set with exceptions: its rows go out in whole workgroups' worth.  The lanes of a wave serve each
+    // other at the sites of the suffix they share, and a workgroup takes its chains' worth of consecutive jobs: with 1024 rows per
+    // suffix (the full matrix in one launch) the workgroups straddle the suffixes and a wave's lanes stop sharing theirs -- ten runs
+    // of N per Mbp 443 k pair-compr./s where 84 rows per launch give 512 k, 100 IUPAC codes 341 against 430 k, 5 % lower case 274
+    // against 309 k.  So such a tile runs as the largest multiple of the workgroup's chains, then the rest (a launch that does not
+    // fill the card: 2 % of a 1024-row matrix).
+    uint32_t rows_a = (tile && tile->rows > 0) ? tile->rows : 0u, rows_b = 0u;
+    if (rows_a && c->any_exc && !singles && n_fast) {
+        uint32_t gl = 0, gs = 0;
+        if (fast_geometry(c, &gl, &gs) != SNK_OK) return SNK_E_ARG;
+        const uint32_t cwg = gl * (uint32_t)c->fast_waves - gs;
+        if (cwg && rows_a > cwg && rows_a % cwg) { rows_b = rows_a % cwg; rows_a -= rows_b; }
+    }
+    uint32_t *const d_out_all = d_out;
     for (int grp = 0; grp < 2; ++grp) {
-        const size_t nf_g = grp == 0 ? (n_clean ? n_clean : n_fast) : (n_clean ? n_fast - n_clean : 0);
+        const size_t nf_g = rows_b ? (size_t)(grp == 0 ? rows_a : rows_b) * tile->n
+                                   : grp == 0 ? (n_clean ? n_clean : n_fast) : (n_clean ? n_fast - n_clean : 0);
         if (!nf_g) continue;
+        uint32_t *const d_out = d_out_all + (rows_b && grp == 1 ? (size_t)rows_a * tile->n : 0);      // (this part's rows)
         const SnkJob *const jl_g = grp == 0 ? d_jobs : d_jobs + n_clean;
         uint32_t waves = (uint32_t)c->fast_waves;
         const bool exc = c->any_exc && !(n_clean && grp == 0);      // some resident 2-bit sequence has exceptions: the instantiations that know about them
@@ -407,7 +423,8 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
         uint32_t far_waves = (!c->any_exc && !singles && c->far_lanes > 0) ? (uint32_t)c->far_waves : 0u;
         if (far_waves && (waves + far_waves > 8u || nf_g < (size_t)c->far_min * chains * (size_t)std::max(c->n_cus, 1))) far_waves = 0u;
         G.jobs = dense ? nullptr : jl_g; G.n_jobs = (uint32_t)nf_g;
-        G.r0 = dense ? tile->r0 : 0u; G.rows = dense ? tile->rows : 1u; G.n = dense ? tile->n : 1u;
+        G.r0 = dense ? tile->r0 + (rows_b && grp == 1 ? rows_a : 0u) : 0u;
+        G.rows = dense ? (rows_b ? (grp == 0 ? rows_a : rows_b) : tile->rows) : 1u; G.n = dense ? tile->n : 1u;
         G.batch = lanes; G.queue = nullptr; G.yorder = nullptr;
         const bool spec = c->fast_spec != 0 && far_waves == 0u && lanes <= 32u;       // two lanes per chain
         const void *fk = singles ? (exc ? (spec ? (const void *)snk_fastx_singles_kernel : (const void *)snk_fastx_singles_one_kernel)

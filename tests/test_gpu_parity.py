@@ -479,6 +479,32 @@ def test_clean_pairs_of_a_set_with_exceptions_run_on_the_pure_kernel(hip, oracle
             assert np.array_equal(lst, np.array([exp[i, j] for i, j in ij], dtype=np.uint32))
 
 
+def test_tiles_of_sets_with_exceptions_go_out_in_whole_workgroups(hip, oracle_mod):
+    """(round 4) A dense tile of a set with exceptions runs as the largest multiple of the workgroup's chains, then the rest, so
+    that the lanes of a wave keep sharing their suffix: 100 sequences of ~70 kbp -- 84 + 16 rows with N runs only, 83 + 17 with a
+    soft-masked sequence in the set -- every size against the oracle, whole matrix and a row range."""
+    o = oracle_mod
+    rng = np.random.default_rng(913)
+    base = [o.lcg_genome(500 + i, 66000 + 97 * i) for i in range(100)]
+    for with_soft in (False, True):
+        seqs = []
+        for i, a in enumerate(base):
+            a = a.copy()
+            if i % 3 == 0:
+                p0 = int(rng.integers(1000, a.size - 1000)); a[p0:p0 + int(rng.integers(1, 90))] = ord("N")
+            if with_soft and i == 50:
+                a[20000:20600] |= 0x20
+            seqs.append(a)
+        exp = np.array([[o.lz4f_size_pair(a, b) for b in seqs] for a in seqs], dtype=np.uint32)
+        with hip.HipContext(0) as ctx:
+            ctx.upload(seqs)
+            assert ctx.num_packed == 100 and ctx.fast_chains() == (83 if with_soft else 84)
+            got = ctx.pairs()
+            part = ctx.pairs(3, 98)
+        assert np.array_equal(got, exp), (with_soft, np.argwhere(got != exp)[:6].tolist())
+        assert np.array_equal(part, exp[3:98])
+
+
 def test_fast_chains_reports_the_workgroup_geometry(hip):
     """snk_fast_chains: lanes x waves of a 2-bit kernel workgroup; fast_lanes = 0 (the default) takes as many chains as the
     160 KiB of LDS hold beside the slot LUT: 84 at 4 waves, and explicit settings are reported as given or refused."""
