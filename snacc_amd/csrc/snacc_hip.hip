@@ -380,9 +380,9 @@ int launch_jobs(snk_ctx_impl *c, hipStream_t st, const SnkJob *d_jobs, size_t n_
     // suffix (the full matrix in one launch) the workgroups straddle the suffixes and a wave's lanes stop sharing theirs -- ten runs
     // of N per Mbp 443 k pair-compr./s where 84 rows per launch give 512 k, 100 IUPAC codes 341 against 430 k, 5 % lower case 274
     // against 309 k.  So such a tile runs as the largest multiple of the workgroup's chains, then the rest (a launch that does not
-    // fill the card: 2 % of a 1024-row matrix).
+    // fill the card: 2 % of a 1024-row matrix).  Pure sets gain a little too (the L1 serves a wave one suffix): 579 -> 584 k.
     uint32_t rows_a = (tile && tile->rows > 0) ? tile->rows : 0u, rows_b = 0u;
-    if (rows_a && c->any_exc && !singles && n_fast) {
+    if (rows_a && !singles && n_fast && (c->any_exc || (c->fast_spec <= 1 && c->far_lanes == 0))) {
         uint32_t gl = 0, gs = 0;
         if (fast_geometry(c, &gl, &gs) != SNK_OK) return SNK_E_ARG;
         const uint32_t cwg = gl * (uint32_t)c->fast_waves - gs;
